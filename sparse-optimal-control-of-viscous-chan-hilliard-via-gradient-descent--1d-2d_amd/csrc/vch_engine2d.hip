@@ -1,0 +1,1106 @@
+// vch_engine2d.hip — host side of the 2D engine: context, launch sequencing, C ABI (include/vch.h).
+//
+// One context = one GPU, one HIP stream, B independent trajectories.  All per-trajectory
+// decisions are taken on the device (TrajState + `fin` kernels); the host only decides how many
+// more launches to enqueue, reading the B state records back once per Newton iteration.
+#include "vch_common.h"
+#include "vch_kernels2d.h"
+#include "vch_gemm.h"
+#include <algorithm>
+#include <cmath>
+
+thread_local char g_vch_err[512] = "";
+
+extern "C" const char *vch_last_error(void) { return g_vch_err; }
+extern "C" int vch_abi_version(void) { return 1; }
+extern "C" int vch_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return -1;
+    return n;
+}
+
+struct vch2d_ctx {
+    vch2d_params prm;
+    int B, Mmax, device;
+    Geom G;
+    Phys P;
+    double hx, hy;
+    hipStream_t stream;
+    hipEvent_t ev0, ev1;
+    dim3 grid;
+    int nblk;
+    long slot_stride;
+    // Newton iterate, two slots each: [2][B][plane]
+    double *phi_s, *mu_s, *Rphi_s, *rhs_s, *D_s;
+    // work planes [B][plane]
+    double *w, *wnew, *mu0, *cphi, *cmu, *x, *r, *dmu, *t1, *t2;
+    double *tmp[6];
+    double *wts_mass, *W_cost;            // single planes
+    double *part;                         // [B][nblk][NPART]
+    TrajState *st, *st_host;
+    double *hist_dev, *hist_host;         // [B][HIST_CAP]
+    // DCT-I matrices and eigenvalues
+    double *Q1f, *Q2f, *Q1s, *Q2s, *mf, *ms;
+    // resident histories [B][Mmax+1][plane] (lazy)
+    double *phi_hist, *u_hist, *u_trial, *phi_trial, *phiQ, *r_hist, *p_hist, *q_hist;
+    double *phiT, *phi0;                  // [B][plane]
+    double *cost_part, *cost_lvl;         // cost partials
+    double *cost_lvl_host;
+    double *alpha_dev;
+    int M_res;                            // steps of the resident state history (-1 none)
+    int u_rows_res;                       // rows of the resident control (0 none)
+    // resident PGD problem
+    bool pgd_ready;
+    bool ramp;
+    double rampT;
+    std::vector<double> t_hist, dt, xg, yg, tfrac;
+    double *tfrac_dev;
+    vch_opt_params opt;
+    std::vector<double> pgd_cost, pgd_alpha_prev, pgd_J;    // per trajectory
+    std::vector<int> pgd_plateau, pgd_done, pgd_k;
+    std::vector<std::vector<double>> pgd_cost_hist;
+    double *J_dev;
+    // knobs
+    int lin_maxit;
+    double lin_tol;
+};
+
+#define LAUNCH(kern, grid, block, ...)                                             \
+    do {                                                                           \
+        hipLaunchKernelGGL(kern, grid, block, 0, c->stream, __VA_ARGS__);          \
+        hipError_t e_ = hipGetLastError();                                         \
+        if (e_ != hipSuccess)                                                      \
+            return vch_fail(VCH_ERR_HIP, "launch %s: %s", #kern, hipGetErrorString(e_)); \
+    } while (0)
+
+static int dalloc(double **p, size_t n, hipStream_t s) {
+    *p = nullptr;
+    HIPCHK(hipMalloc((void **)p, n * sizeof(double)));
+    HIPCHK(hipMemsetAsync(*p, 0, n * sizeof(double), s));
+    return 0;
+}
+
+// host [nplanes][ns][nf] contiguous  <->  device [nplanes][ns][pitch]
+static int h2d(vch2d_ctx *c, double *dev, const double *host, long nplanes) {
+    HIPCHK(hipMemcpy2DAsync(dev, (size_t)c->G.pitch * 8, host, (size_t)c->G.nf * 8, (size_t)c->G.nf * 8,
+                            (size_t)c->G.ns * nplanes, hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+static int d2h(vch2d_ctx *c, double *host, const double *dev, long nplanes) {
+    HIPCHK(hipMemcpy2DAsync(host, (size_t)c->G.nf * 8, dev, (size_t)c->G.pitch * 8, (size_t)c->G.nf * 8,
+                            (size_t)c->G.ns * nplanes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+// histories: host [B][rows][ns][nf] <-> device [B][rows_alloc][plane]
+static int h2d_hist(vch2d_ctx *c, double *dev, const double *host, int rows) {
+    const long hs = (long)(c->Mmax + 1) * c->G.plane;
+    for (int b = 0; b < c->B; ++b)
+        VCHCHK(h2d(c, dev + b * hs, host + (long)b * rows * c->G.nf * c->G.ns, rows));
+    return 0;
+}
+static int d2h_hist(vch2d_ctx *c, double *host, const double *dev, int rows) {
+    const long hs = (long)(c->Mmax + 1) * c->G.plane;
+    for (int b = 0; b < c->B; ++b) {
+        HIPCHK(hipMemcpy2DAsync(host + (long)b * rows * c->G.nf * c->G.ns, (size_t)c->G.nf * 8, dev + b * hs,
+                                (size_t)c->G.pitch * 8, (size_t)c->G.nf * 8, (size_t)c->G.ns * rows,
+                                hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+static int ensure_hist(vch2d_ctx *c, double **p) {
+    if (*p) return 0;
+    size_t n = (size_t)c->B * (c->Mmax + 1) * c->G.plane;
+    hipError_t e = hipMalloc((void **)p, n * sizeof(double));
+    if (e != hipSuccess) {
+        *p = nullptr;
+        return vch_fail(VCH_ERR_NOMEM, "hipMalloc of a %.2f GB history failed: %s", n * 8e-9, hipGetErrorString(e));
+    }
+    HIPCHK(hipMemsetAsync(*p, 0, n * sizeof(double), c->stream));
+    return 0;
+}
+static inline long hist_stride(const vch2d_ctx *c) { return (long)(c->Mmax + 1) * c->G.plane; }
+
+static int sync_state(vch2d_ctx *c) {
+    HIPCHK(hipMemcpyAsync(c->st_host, c->st, sizeof(TrajState) * c->B, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// DCT-I matrices Q1 = S C^ and Q2 = C^ S^-1 and eigenvalues of the 1-D factor of M = -L.
+static void dct_tables(int N, double h, std::vector<double> &Q1, std::vector<double> &Q2, std::vector<double> &m) {
+    const int n = N + 1;
+    Q1.assign((size_t)n * n, 0.0);
+    Q2.assign((size_t)n * n, 0.0);
+    m.assign(n, 0.0);
+    const long double pi = 3.14159265358979323846264338327950288L;
+    const long double sc = sqrtl(2.0L / N), is2 = 1.0L / sqrtl(2.0L);
+    for (int j = 0; j < n; ++j) {
+        long double sj = (j == 0 || j == N) ? is2 : 1.0L;
+        for (int k = 0; k < n; ++k) {
+            long double sk = (k == 0 || k == N) ? is2 : 1.0L;
+            // exact argument reduction: cos(pi * (j k mod 2N) / N)
+            long long jk = ((long long)j * k) % (2LL * N);
+            long double cv = cosl(pi * (long double)jk / (long double)N);
+            Q1[(size_t)j * n + k] = (double)(sc * sj * sj * sk * cv);
+            Q2[(size_t)j * n + k] = (double)(sc * sj * cv);
+        }
+        m[j] = (double)((2.0L - 2.0L * cosl(pi * j / (long double)N)) / ((long double)h * h));
+    }
+}
+
+extern "C" vch2d_ctx *vch2d_create(const vch2d_params *p, int batch, int max_steps, int device) {
+    if (!p || p->Nx < 2 || p->Ny < 2 || batch < 1 || max_steps < 1 || !(p->Lx > 0) || !(p->Ly > 0)) {
+        vch_fail(VCH_ERR_ARG, "vch2d_create: bad arguments (Nx,Ny >= 2, batch >= 1, max_steps >= 1)");
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) {
+        vch_fail(VCH_ERR_HIP, "hipSetDevice(%d) failed", device);
+        return nullptr;
+    }
+    vch2d_ctx *c = new vch2d_ctx();
+    c->prm = *p;
+    c->B = batch;
+    c->Mmax = max_steps;
+    c->device = device;
+    c->hx = p->Lx / p->Nx;
+    c->hy = p->Ly / p->Ny;
+    Geom &G = c->G;
+    G.nf = p->Nx + 1;
+    G.ns = p->Ny + 1;
+    G.pitch = (G.nf + 7) / 8 * 8;
+    G.plane = (long)G.ns * G.pitch;
+    G.tiles_f = (G.nf + TX - 1) / TX;
+    G.tiles_s = (G.ns + TY - 1) / TY;
+    G.ax = 1.0 / (c->hx * c->hx);
+    G.ay = 1.0 / (c->hy * c->hy);
+    c->P = Phys{p->tau, p->gamma, p->c1, p->c2, p->kappa, p->Lx * p->Ly};
+    c->grid = dim3(G.tiles_f, G.tiles_s, batch);
+    c->nblk = G.tiles_f * G.tiles_s;
+    c->slot_stride = (long)batch * G.plane;
+    c->M_res = -1;
+    c->u_rows_res = 0;
+    c->pgd_ready = false;
+    c->lin_maxit = 600;
+    c->lin_tol = 1e-15;
+    auto fail = [&](const char *what) {
+        vch_fail(VCH_ERR_HIP, "vch2d_create: %s failed: %s", what, hipGetErrorString(hipGetLastError()));
+        return (vch2d_ctx *)nullptr;
+    };
+    if (hipStreamCreate(&c->stream) != hipSuccess) return fail("hipStreamCreate");
+    hipEventCreate(&c->ev0);
+    hipEventCreate(&c->ev1);
+    const size_t bp = (size_t)batch * G.plane;
+    double **two[] = {&c->phi_s, &c->mu_s, &c->Rphi_s, &c->rhs_s, &c->D_s};
+    for (auto q : two)
+        if (dalloc(q, 2 * bp, c->stream)) return fail("hipMalloc");
+    double **one[] = {&c->w, &c->wnew, &c->mu0, &c->cphi, &c->cmu, &c->x, &c->r, &c->dmu, &c->t1, &c->t2,
+                      &c->tmp[0], &c->tmp[1], &c->tmp[2], &c->tmp[3], &c->tmp[4], &c->tmp[5], &c->phiT, &c->phi0};
+    for (auto q : one)
+        if (dalloc(q, bp, c->stream)) return fail("hipMalloc");
+    if (dalloc(&c->wts_mass, G.plane, c->stream) || dalloc(&c->W_cost, G.plane, c->stream)) return fail("hipMalloc");
+    if (dalloc(&c->part, (size_t)batch * c->nblk * NPART, c->stream)) return fail("hipMalloc");
+    if (dalloc(&c->hist_dev, (size_t)batch * HIST_CAP, c->stream)) return fail("hipMalloc");
+    if (dalloc(&c->alpha_dev, batch, c->stream) || dalloc(&c->J_dev, 5 * (size_t)batch, c->stream)) return fail("hipMalloc");
+    if (hipMalloc((void **)&c->st, sizeof(TrajState) * batch) != hipSuccess) return fail("hipMalloc");
+    hipMemsetAsync(c->st, 0, sizeof(TrajState) * batch, c->stream);
+    if (hipHostMalloc((void **)&c->st_host, sizeof(TrajState) * batch) != hipSuccess) return fail("hipHostMalloc");
+    if (hipHostMalloc((void **)&c->hist_host, sizeof(double) * batch * HIST_CAP) != hipSuccess) return fail("hipHostMalloc");
+    c->phi_hist = c->u_hist = c->u_trial = c->phi_trial = c->phiQ = c->r_hist = c->p_hist = c->q_hist = nullptr;
+    c->cost_part = c->cost_lvl = nullptr;
+    c->cost_lvl_host = nullptr;
+    c->tfrac_dev = nullptr;
+    // mass weights hx*hy*outer(trapz(Nx+1), trapz(Ny+1)) on the TRUE (i, j) of each flat entry (F2:528-531)
+    {
+        std::vector<double> wm((size_t)G.plane, 0.0);
+        const int nx1 = p->Nx + 1, ny1 = p->Ny + 1;
+        for (int i = 0; i < nx1; ++i)
+            for (int j = 0; j < ny1; ++j) {
+                long f = (long)i * ny1 + j;
+                double wi = (i == 0 || i == nx1 - 1) ? 0.5 : 1.0, wj = (j == 0 || j == ny1 - 1) ? 0.5 : 1.0;
+                wm[(f / G.nf) * G.pitch + (f % G.nf)] = c->hx * c->hy * (wi * wj);
+            }
+        if (hipMemcpy(c->wts_mass, wm.data(), wm.size() * 8, hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy");
+    }
+    // DCT tables
+    {
+        std::vector<double> Q1, Q2, m;
+        auto up = [&](double **d, const std::vector<double> &v) {
+            if (hipMalloc((void **)d, v.size() * 8) != hipSuccess) return false;
+            return hipMemcpy(*d, v.data(), v.size() * 8, hipMemcpyHostToDevice) == hipSuccess;
+        };
+        dct_tables(p->Nx, c->hx, Q1, Q2, m);
+        if (!up(&c->Q1f, Q1) || !up(&c->Q2f, Q2) || !up(&c->mf, m)) return fail("DCT table upload");
+        dct_tables(p->Ny, c->hy, Q1, Q2, m);
+        if (!up(&c->Q1s, Q1) || !up(&c->Q2s, Q2) || !up(&c->ms, m)) return fail("DCT table upload");
+    }
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return fail("hipStreamSynchronize");
+    return c;
+}
+
+extern "C" void vch2d_destroy(vch2d_ctx *c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    double *all[] = {c->phi_s, c->mu_s, c->Rphi_s, c->rhs_s, c->D_s, c->w, c->wnew, c->mu0, c->cphi, c->cmu, c->x,
+                     c->r, c->dmu, c->t1, c->t2, c->tmp[0], c->tmp[1], c->tmp[2], c->tmp[3], c->tmp[4], c->tmp[5],
+                     c->phiT, c->phi0, c->wts_mass, c->W_cost, c->part, c->hist_dev, c->alpha_dev, c->J_dev, c->Q1f,
+                     c->Q2f, c->Q1s, c->Q2s, c->mf, c->ms, c->phi_hist, c->u_hist, c->u_trial, c->phi_trial, c->phiQ,
+                     c->r_hist, c->p_hist, c->q_hist, c->cost_part, c->cost_lvl, c->tfrac_dev};
+    for (double *q : all)
+        if (q) hipFree(q);
+    hipFree(c->st);
+    hipHostFree(c->st_host);
+    hipHostFree(c->hist_host);
+    if (c->cost_lvl_host) hipHostFree(c->cost_lvl_host);
+    hipEventDestroy(c->ev0);
+    hipEventDestroy(c->ev1);
+    hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int vch2d_batch(const vch2d_ctx *c) { return c ? c->B : VCH_ERR_ARG; }
+
+#define CTXCHK(c)                                                         \
+    do {                                                                  \
+        if (!(c)) return vch_fail(VCH_ERR_ARG, "%s: NULL context", __func__); \
+        HIPCHK(hipSetDevice((c)->device));                                \
+    } while (0)
+#define ARGCHK(cond, msg)                                             \
+    do {                                                              \
+        if (!(cond)) return vch_fail(VCH_ERR_ARG, "%s: %s", __func__, msg); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------
+// fast-diagonalisation preconditioner:  out (+)= (c0 + m (c1a + c1b dbar + c2 m))^-1 in
+// ------------------------------------------------------------------------------------
+static int precond(vch2d_ctx *c, const double *in, long in_slot_stride, double *out, bool accumulate,
+                   double c0, double c1a, double c1b, double c2, int gate) {
+    const Geom &G = c->G;
+    const int ns = G.ns, nf = G.nf;
+    dim3 g((nf + GN - 1) / GN, (ns + GM - 1) / GM, c->B);
+    SpecArgs sp{c0, c1a, c1b, c2, c->ms, c->mf};
+    // T1 = g Q1f
+    LAUNCH((k_gemm<false, 0>), g, dim3(256), ns, nf, nf, in, (long)G.pitch, G.plane, in_slot_stride, c->Q1f, (long)nf, 0L,
+           c->t1, (long)G.pitch, G.plane, sp, c->st, gate);
+    // T2 = (Q1s^T T1) o mult
+    LAUNCH((k_gemm<true, 1>), g, dim3(256), ns, nf, ns, c->Q1s, (long)ns, 0L, 0L, c->t1, (long)G.pitch, G.plane, c->t2,
+           (long)G.pitch, G.plane, sp, c->st, gate);
+    // T3 = Q2s^T T2
+    LAUNCH((k_gemm<true, 0>), g, dim3(256), ns, nf, ns, c->Q2s, (long)ns, 0L, 0L, c->t2, (long)G.pitch, G.plane, c->t1,
+           (long)G.pitch, G.plane, sp, c->st, gate);
+    // out (+)= T3 Q2f
+    if (accumulate)
+        LAUNCH((k_gemm<false, 2>), g, dim3(256), ns, nf, nf, c->t1, (long)G.pitch, G.plane, 0L, c->Q2f, (long)nf, 0L, out,
+               (long)G.pitch, G.plane, sp, c->st, gate);
+    else
+        LAUNCH((k_gemm<false, 0>), g, dim3(256), ns, nf, nf, c->t1, (long)G.pitch, G.plane, 0L, c->Q2f, (long)nf, 0L, out,
+               (long)G.pitch, G.plane, sp, c->st, gate);
+    return 0;
+}
+
+// number of Richardson sweeps to enqueue for the worst contraction bound of the batch
+static int sweeps_for(const vch2d_ctx *c, bool only_newton_active) {
+    double rho = 0.0;
+    bool any = false;
+    for (int b = 0; b < c->B; ++b) {
+        const TrajState &S = c->st_host[b];
+        if (!S.lin_active) continue;
+        if (only_newton_active && !S.newton_active) continue;
+        any = true;
+        rho = std::max(rho, S.rho);
+    }
+    if (!any) return 0;
+    if (!(rho < 0.999)) return c->lin_maxit;
+    if (rho < 1e-12) return 3;
+    int n = (int)std::ceil(std::log(1e-16) / std::log(rho)) + 3;
+    return std::max(3, std::min(n, c->lin_maxit));
+}
+
+// Richardson sweeps on the Schur system of the current Newton iterate; x := dphi.
+static int schur_solve(vch2d_ctx *c, double dt, int nsweeps) {
+    for (int it = 0; it < nsweeps; ++it) {
+        if (it == 0)      // x = P^-1 rhs
+            VCHCHK(precond(c, c->rhs_s, c->slot_stride, c->x, false, 1.0 / dt, 0.0, 1.0, 0.5 * c->P.kappa, 1));
+        else
+            VCHCHK(precond(c, c->r, 0, c->x, true, 1.0 / dt, 0.0, 1.0, 0.5 * c->P.kappa, 1));
+        LAUNCH((k_schur<1>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->x, c->D_s, c->rhs_s, dt, c->r,
+               c->part);
+        LAUNCH(k_fin_lin, dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->lin_tol, c->lin_maxit);
+    }
+    return 0;
+}
+
+// One implicit time level for the whole batch (F2:323-427).  On entry the old level is
+// (phi_s, mu_s)[slot], w; on exit the new iterate is in (phi_s, mu_s)[slot] and w_new in c->wnew.
+static int newton_level(vch2d_ctx *c, double dt, const double *un, const double *unp1, long u_stride,
+                        const double *wnew_in) {
+    LAUNCH(k_prepare, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s, c->w, un, unp1, u_stride,
+           wnew_in, dt, c->wnew, c->mu0, c->cphi, c->cmu);
+    LAUNCH(k_fin_newton_begin, dim3(c->B), dim3(64), c->st);
+    LAUNCH((k_residual<0>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s, c->Rphi_s, c->rhs_s,
+           c->D_s, c->mu0, c->x, c->dmu, c->cphi, c->cmu, dt, c->part);
+    LAUNCH((k_fin_residual<0>), dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->hist_dev, c->P.kappa, dt);
+    VCHCHK(sync_state(c));
+    auto any_active = [&]() {
+        for (int b = 0; b < c->B; ++b)
+            if (c->st_host[b].newton_active) return true;
+        return false;
+    };
+    auto any_trial = [&]() {
+        for (int b = 0; b < c->B; ++b)
+            if (c->st_host[b].newton_active && c->st_host[b].need_trial) return true;
+        return false;
+    };
+    int guard = 0;
+    while (any_active()) {
+        if (++guard > NEWTON_MAXIT + 2) return vch_fail(VCH_ERR_STATE, "newton_level: state machine did not terminate");
+        VCHCHK(schur_solve(c, dt, sweeps_for(c, true)));
+        LAUNCH(k_dmu_ceiling, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->x, c->phi_s, c->D_s, c->Rphi_s,
+               c->dmu, c->part);
+        LAUNCH(k_fin_ceiling, dim3(c->B), dim3(64), c->st, c->part, c->nblk);
+        int tguard = 0;
+        do {
+            LAUNCH((k_residual<1>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s, c->Rphi_s,
+                   c->rhs_s, c->D_s, c->mu0, c->x, c->dmu, c->cphi, c->cmu, dt, c->part);
+            LAUNCH((k_fin_residual<1>), dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->hist_dev, c->P.kappa, dt);
+            VCHCHK(sync_state(c));
+            if (++tguard > ARMIJO_TRIALS + 2) return vch_fail(VCH_ERR_STATE, "newton_level: Armijo loop did not terminate");
+        } while (any_trial());
+    }
+    return 0;
+}
+
+static void fill_stats(vch2d_ctx *c, vch_stats *s, float ms) {
+    if (!s) return;
+    memset(s, 0, sizeof(*s));
+    for (int b = 0; b < c->B; ++b) {
+        const TrajState &S = c->st_host[b];
+        s->newton_iters += S.newton_total;
+        s->linear_solves += S.nsolves;
+        s->linear_iters += S.lin_total;
+        s->armijo_trials += S.ntrials;
+        s->max_lin_relres = std::max(s->max_lin_relres, S.lin_maxrel);
+    }
+    s->seconds = ms * 1e-3;
+}
+
+static int reset_counters(vch2d_ctx *c) {
+    HIPCHK(hipMemsetAsync(c->st, 0, sizeof(TrajState) * c->B, c->stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// operator-level entry points
+// ------------------------------------------------------------------------------------
+extern "C" int vch2d_apply_laplacian(vch2d_ctx *c, const double *v, double *out) {
+    CTXCHK(c);
+    ARGCHK(v && out, "NULL array");
+    VCHCHK(h2d(c, c->tmp[0], v, c->B));
+    LAUNCH(k_lap, c->grid, dim3(NTH), c->G, c->tmp[0], c->tmp[1]);
+    return d2h(c, out, c->tmp[1], c->B);
+}
+
+extern "C" int vch2d_initialize_mu(vch2d_ctx *c, const double *phi, const double *w, double *mu_out) {
+    CTXCHK(c);
+    ARGCHK(phi && w && mu_out, "NULL array");
+    VCHCHK(h2d(c, c->tmp[0], phi, c->B));
+    VCHCHK(h2d(c, c->tmp[1], w, c->B));
+    LAUNCH(k_init_mu, c->grid, dim3(NTH), c->G, c->P, c->tmp[0], c->tmp[1], c->tmp[2]);
+    return d2h(c, mu_out, c->tmp[2], c->B);
+}
+
+extern "C" int vch2d_solve_w(vch2d_ctx *c, const double *w_old, double dt, const double *u_n, const double *u_np1,
+                             double *w_out) {
+    CTXCHK(c);
+    ARGCHK(w_old && w_out && dt > 0, "NULL array or dt <= 0");
+    VCHCHK(h2d(c, c->tmp[0], w_old, c->B));
+    if (u_n) VCHCHK(h2d(c, c->tmp[1], u_n, c->B));
+    if (u_np1) VCHCHK(h2d(c, c->tmp[2], u_np1, c->B));
+    LAUNCH(k_solve_w, c->grid, dim3(NTH), c->G, c->tmp[0], u_n ? c->tmp[1] : nullptr, u_np1 ? c->tmp[2] : nullptr,
+           c->P.gamma / dt, c->tmp[3]);
+    return d2h(c, w_out, c->tmp[3], c->B);
+}
+
+static int read_norms(vch2d_ctx *c, int slot, double *norm_out) {
+    // sums partial slot `slot` per trajectory on the host (test helper path)
+    std::vector<double> hp((size_t)c->B * c->nblk * NPART);
+    HIPCHK(hipMemcpyAsync(hp.data(), c->part, hp.size() * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int b = 0; b < c->B; ++b) {
+        double s = 0.0;
+        for (int t = 0; t < c->nblk; ++t) s += hp[((size_t)b * c->nblk + t) * NPART + slot];
+        norm_out[b] = std::sqrt(s);
+    }
+    return 0;
+}
+
+extern "C" int vch2d_residuals(vch2d_ctx *c, const double *pn, const double *po, const double *mn, const double *mo,
+                               const double *wn, const double *wo, double dt, double *Rp, double *Rm, double *norm_out) {
+    CTXCHK(c);
+    ARGCHK(pn && po && mn && mo && wn && wo && Rp && Rm && dt > 0, "NULL array or dt <= 0");
+    const double *src[6] = {pn, po, mn, mo, wn, wo};
+    for (int k = 0; k < 6; ++k) VCHCHK(h2d(c, c->tmp[k], src[k], c->B));
+    LAUNCH(k_residual_plain, c->grid, dim3(NTH), c->G, c->P, c->tmp[0], c->tmp[1], c->tmp[2], c->tmp[3], c->tmp[4],
+           c->tmp[5], dt, c->t1, c->t2, c->part);
+    VCHCHK(d2h(c, Rp, c->t1, c->B));
+    VCHCHK(d2h(c, Rm, c->t2, c->B));
+    if (norm_out) VCHCHK(read_norms(c, 0, norm_out));
+    return 0;
+}
+
+extern "C" int vch2d_jacobian_apply(vch2d_ctx *c, const double *phi_new, double dt, const double *dphi, const double *dmu,
+                                    double *out_phi, double *out_mu) {
+    CTXCHK(c);
+    ARGCHK(phi_new && dphi && dmu && out_phi && out_mu && dt > 0, "NULL array or dt <= 0");
+    VCHCHK(h2d(c, c->tmp[0], phi_new, c->B));
+    VCHCHK(h2d(c, c->tmp[1], dphi, c->B));
+    VCHCHK(h2d(c, c->tmp[2], dmu, c->B));
+    LAUNCH(k_jac_apply, c->grid, dim3(NTH), c->G, c->P, c->tmp[0], c->tmp[1], c->tmp[2], dt, c->tmp[3], c->tmp[4]);
+    VCHCHK(d2h(c, out_phi, c->tmp[3], c->B));
+    return d2h(c, out_mu, c->tmp[4], c->B);
+}
+
+extern "C" int vch2d_schur_apply(vch2d_ctx *c, const double *phi_new, double dt, const double *x, double *out) {
+    CTXCHK(c);
+    ARGCHK(phi_new && x && out && dt > 0, "NULL array or dt <= 0");
+    VCHCHK(reset_counters(c));
+    VCHCHK(h2d(c, c->tmp[0], phi_new, c->B));
+    VCHCHK(h2d(c, c->tmp[1], x, c->B));
+    // D into slot 0 through the solve set-up kernel (a = b = x, results other than D unused)
+    LAUNCH(k_solve_setup, c->grid, dim3(NTH), c->G, c->P, c->tmp[1], c->tmp[1], c->tmp[0], dt, c->Rphi_s, c->rhs_s, c->D_s,
+           c->part);
+    LAUNCH((k_schur<0>), c->grid, dim3(NTH), c->G, c->P, (const TrajState *)nullptr, c->slot_stride, c->tmp[1], c->D_s,
+           c->rhs_s, dt, c->tmp[2], c->part);
+    return d2h(c, out, c->tmp[2], c->B);
+}
+
+extern "C" int vch2d_spectral_solve(vch2d_ctx *c, double c0, double c1, double c2, const double *v, double *out) {
+    CTXCHK(c);
+    ARGCHK(v && out, "NULL array");
+    VCHCHK(h2d(c, c->tmp[0], v, c->B));
+    VCHCHK(precond(c, c->tmp[0], 0, c->tmp[1], false, c0, c1, 0.0, c2, 0));
+    return d2h(c, out, c->tmp[1], c->B);
+}
+
+extern "C" int vch2d_jacobian_solve(vch2d_ctx *c, const double *phi_new, double dt, const double *rhs_phi,
+                                    const double *rhs_mu, double *dphi, double *dmu, vch_stats *stats) {
+    CTXCHK(c);
+    ARGCHK(phi_new && rhs_phi && rhs_mu && dphi && dmu && dt > 0, "NULL array or dt <= 0");
+    VCHCHK(reset_counters(c));
+    HIPCHK(hipEventRecord(c->ev0, c->stream));
+    VCHCHK(h2d(c, c->tmp[0], phi_new, c->B));
+    VCHCHK(h2d(c, c->tmp[1], rhs_phi, c->B));
+    VCHCHK(h2d(c, c->tmp[2], rhs_mu, c->B));
+    // slot 0: phi, R_phi = -a, rhs = b - L a, D
+    HIPCHK(hipMemcpyAsync(c->phi_s, c->tmp[0], sizeof(double) * c->B * c->G.plane, hipMemcpyDeviceToDevice, c->stream));
+    LAUNCH(k_solve_setup, c->grid, dim3(NTH), c->G, c->P, c->tmp[1], c->tmp[2], c->tmp[0], dt, c->Rphi_s, c->rhs_s, c->D_s,
+           c->part);
+    LAUNCH(k_fin_lin_begin, dim3(c->B), dim3(64), c->st, c->part, c->nblk, 2, c->P.tau, c->P.kappa, dt);
+    VCHCHK(sync_state(c));
+    VCHCHK(schur_solve(c, dt, sweeps_for(c, false)));
+    // back substitution needs newton_active && !need_trial
+    HIPCHK(hipStreamSynchronize(c->stream));
+    {   // keep the device-side linear-solve results, flip only the two flags
+        std::vector<TrajState> tmp(c->B);
+        HIPCHK(hipMemcpy(tmp.data(), c->st, sizeof(TrajState) * c->B, hipMemcpyDeviceToHost));
+        for (auto &S : tmp) { S.newton_active = 1; S.need_trial = 0; }
+        HIPCHK(hipMemcpy(c->st, tmp.data(), sizeof(TrajState) * c->B, hipMemcpyHostToDevice));
+    }
+    LAUNCH(k_dmu_ceiling, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->x, c->phi_s, c->D_s, c->Rphi_s, c->dmu,
+           c->part);
+    LAUNCH(k_fin_ceiling, dim3(c->B), dim3(64), c->st, c->part, c->nblk);
+    HIPCHK(hipEventRecord(c->ev1, c->stream));
+    VCHCHK(d2h(c, dphi, c->x, c->B));
+    VCHCHK(d2h(c, dmu, c->dmu, c->B));
+    VCHCHK(sync_state(c));
+    float ms = 0;
+    hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    fill_stats(c, stats, ms);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// adjoint operator / solve
+// ------------------------------------------------------------------------------------
+// Richardson sweeps for A(phi_n) x = rhs (buffers: x = c->x, rhs = c->cphi, D_n = c->cmu, r = c->r)
+static int adjoint_solve_sweeps(vch2d_ctx *c, double dt, int nsweeps) {
+    // initial residual of the initial guess
+    LAUNCH((k_adj_op<1>), c->grid, dim3(NTH), c->G, c->P, c->st, c->x, c->cmu, c->cphi, dt, c->r, c->part);
+    LAUNCH(k_fin_lin, dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->lin_tol, c->lin_maxit);
+    for (int it = 0; it < nsweeps; ++it) {
+        VCHCHK(precond(c, c->r, 0, c->x, true, 1.0, c->P.tau, 0.5 * dt, 0.5 * dt, 1));
+        LAUNCH((k_adj_op<1>), c->grid, dim3(NTH), c->G, c->P, c->st, c->x, c->cmu, c->cphi, dt, c->r, c->part);
+        LAUNCH(k_fin_lin, dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->lin_tol, c->lin_maxit);
+    }
+    return 0;
+}
+
+extern "C" int vch2d_adjoint_apply(vch2d_ctx *c, int which, const double *phi, double dt, const double *v, double *out) {
+    CTXCHK(c);
+    ARGCHK(phi && v && out && (which == 0 || which == 1), "NULL array or which not in {0,1}");
+    VCHCHK(h2d(c, c->tmp[0], phi, c->B));
+    VCHCHK(h2d(c, c->tmp[1], v, c->B));
+    LAUNCH(k_adj_setup, c->grid, dim3(NTH), c->G, c->P, c->tmp[0], (const double *)nullptr, c->cmu, c->part);
+    if (which == 0)
+        LAUNCH((k_adj_op<0>), c->grid, dim3(NTH), c->G, c->P, c->st, c->tmp[1], c->cmu, c->cphi, dt, c->tmp[2], c->part);
+    else
+        LAUNCH((k_adj_op<2>), c->grid, dim3(NTH), c->G, c->P, c->st, c->tmp[1], c->cmu, c->cphi, dt, c->tmp[2], c->part);
+    return d2h(c, out, c->tmp[2], c->B);
+}
+
+extern "C" int vch2d_adjoint_solve(vch2d_ctx *c, const double *phi_n, double dt, const double *rhs, double *p_out,
+                                   vch_stats *stats) {
+    CTXCHK(c);
+    ARGCHK(rhs && p_out && dt >= 0 && (phi_n || dt == 0), "NULL array or dt < 0");
+    VCHCHK(reset_counters(c));
+    HIPCHK(hipEventRecord(c->ev0, c->stream));
+    if (phi_n) VCHCHK(h2d(c, c->tmp[0], phi_n, c->B));
+    VCHCHK(h2d(c, c->cphi, rhs, c->B));
+    LAUNCH(k_adj_setup, c->grid, dim3(NTH), c->G, c->P, (dt > 0 ? c->tmp[0] : (const double *)nullptr), c->cphi, c->cmu,
+           c->part);
+    LAUNCH(k_fin_lin_begin, dim3(c->B), dim3(64), c->st, c->part, c->nblk, 0, c->P.tau, c->P.kappa, dt);
+    LAUNCH(k_fill, c->grid, dim3(NTH), c->G, c->x, 0.0);
+    VCHCHK(sync_state(c));
+    VCHCHK(adjoint_solve_sweeps(c, dt, sweeps_for(c, false)));
+    HIPCHK(hipEventRecord(c->ev1, c->stream));
+    VCHCHK(d2h(c, p_out, c->x, c->B));
+    VCHCHK(sync_state(c));
+    float ms = 0;
+    hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    fill_stats(c, stats, ms);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// Newton call and forward march
+// ------------------------------------------------------------------------------------
+extern "C" int vch2d_newton_raphson(vch2d_ctx *c, const double *phi_old, const double *mu_old, const double *w_old,
+                                    const double *w_new, double dt, double *phi_new, double *mu_new, double *hist,
+                                    int hist_cap, int32_t *n_hist, vch_stats *stats) {
+    CTXCHK(c);
+    ARGCHK(phi_old && mu_old && w_old && w_new && phi_new && mu_new && dt > 0, "NULL array or dt <= 0");
+    VCHCHK(reset_counters(c));
+    VCHCHK(h2d(c, c->phi_s, phi_old, c->B));
+    VCHCHK(h2d(c, c->mu_s, mu_old, c->B));
+    VCHCHK(h2d(c, c->w, w_old, c->B));
+    VCHCHK(h2d(c, c->tmp[0], w_new, c->B));
+    HIPCHK(hipEventRecord(c->ev0, c->stream));
+    VCHCHK(newton_level(c, dt, nullptr, nullptr, 0, c->tmp[0]));
+    HIPCHK(hipEventRecord(c->ev1, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int b = 0; b < c->B; ++b) {
+        const int slot = c->st_host[b].slot;
+        VCHCHK(d2h(c, phi_new + (long)b * c->G.nf * c->G.ns, c->phi_s + slot * c->slot_stride + b * c->G.plane, 1));
+        VCHCHK(d2h(c, mu_new + (long)b * c->G.nf * c->G.ns, c->mu_s + slot * c->slot_stride + b * c->G.plane, 1));
+    }
+    if (hist || n_hist) {
+        HIPCHK(hipMemcpy(c->hist_host, c->hist_dev, sizeof(double) * c->B * HIST_CAP, hipMemcpyDeviceToHost));
+        for (int b = 0; b < c->B; ++b) {
+            int n = std::min(c->st_host[b].iters, HIST_CAP);
+            if (n_hist) n_hist[b] = n;
+            if (hist)
+                for (int k = 0; k < std::min(n, hist_cap); ++k) hist[(long)b * hist_cap + k] = c->hist_host[(long)b * HIST_CAP + k];
+        }
+    }
+    float ms = 0;
+    hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    fill_stats(c, stats, ms);
+    return 0;
+}
+
+// March M steps from the state in phi_s[slot 0] (already uploaded), control in u_dev
+// ([B][Mmax+1][plane], u_rows valid rows) or NULL; history into hist_dev_out.
+static int forward_core(vch2d_ctx *c, const double *u_dev, int u_rows, const double *dt, int M, double *hist_out) {
+    const long hs = hist_stride(c);
+    // slot 0 holds phi0; w = 0; mu = initialize_mu(phi0, 0) (F2:518-520); mass0 (F2:532)
+    HIPCHK(hipMemsetAsync(c->w, 0, sizeof(double) * c->B * c->G.plane, c->stream));
+    LAUNCH(k_init_mu, c->grid, dim3(NTH), c->G, c->P, c->phi_s, c->w, c->mu_s);
+    LAUNCH(k_mass, c->grid, dim3(NTH), c->G, c->st, c->slot_stride, c->phi_s, c->wts_mass, 0, c->part);
+    LAUNCH(k_fin_mass, dim3(c->B), dim3(64), c->st, c->part, c->nblk, 1);
+    if (hist_out) LAUNCH(k_copy_plane, c->grid, dim3(NTH), c->G, c->phi_s, c->G.plane, hist_out, hs);
+    for (int step = 0; step < M; ++step) {
+        const double *un = nullptr, *unp1 = nullptr;
+        if (u_dev && step < u_rows - 1) {        // F2:545-548
+            un = u_dev + (long)step * c->G.plane;
+            unp1 = u_dev + (long)(step + 1) * c->G.plane;
+        }
+        VCHCHK(newton_level(c, dt[step], un, unp1, hs, nullptr));
+        // clip, mass fix, store (F2:562-585)
+        LAUNCH(k_mass, c->grid, dim3(NTH), c->G, c->st, c->slot_stride, c->phi_s, c->wts_mass, 1, c->part);
+        LAUNCH(k_fin_mass, dim3(c->B), dim3(64), c->st, c->part, c->nblk, 0);
+        LAUNCH(k_post, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s,
+               hist_out ? hist_out + (long)(step + 1) * c->G.plane : (double *)nullptr, hs);
+        std::swap(c->w, c->wnew);
+    }
+    return 0;
+}
+
+extern "C" int vch2d_forward(vch2d_ctx *c, const double *phi0, const double *u, int u_rows, const double *dt, int M,
+                             double *phi_hist_out, vch_stats *stats) {
+    CTXCHK(c);
+    ARGCHK(phi0 && dt && M >= 1 && M <= c->Mmax, "NULL array or M out of range (1..max_steps)");
+    for (int k = 0; k < M; ++k) ARGCHK(dt[k] > 0, "dt must be positive");
+    VCHCHK(ensure_hist(c, &c->phi_hist));
+    const double *u_dev = nullptr;
+    if (u == VCH_RESIDENT) {
+        ARGCHK(c->u_hist && c->u_rows_res > 0, "no resident control");
+        u_dev = c->u_hist;
+        u_rows = c->u_rows_res;
+    } else if (u) {
+        ARGCHK(u_rows >= 1 && u_rows <= c->Mmax + 1, "control rows out of range (1..max_steps+1)");
+        VCHCHK(ensure_hist(c, &c->u_hist));
+        VCHCHK(h2d_hist(c, c->u_hist, u, u_rows));
+        c->u_rows_res = u_rows;
+        u_dev = c->u_hist;
+    }
+    VCHCHK(reset_counters(c));
+    VCHCHK(h2d(c, c->phi_s, phi0, c->B));
+    HIPCHK(hipEventRecord(c->ev0, c->stream));
+    VCHCHK(forward_core(c, u_dev, u_rows, dt, M, c->phi_hist));
+    HIPCHK(hipEventRecord(c->ev1, c->stream));
+    VCHCHK(sync_state(c));
+    c->M_res = M;
+    if (phi_hist_out) VCHCHK(d2h_hist(c, phi_hist_out, c->phi_hist, M + 1));
+    float ms = 0;
+    hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    fill_stats(c, stats, ms);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// adjoint sweep (B2:75-246)
+// ------------------------------------------------------------------------------------
+struct RampArgs {
+    const double *phi0, *phiT, *tfrac;   // device
+};
+
+// phi history in phi_hist_dev ([B][Mmax+1][plane]); targets phiQ_dev (same layout) or NULL, phiT_dev [B][plane] or NULL.
+static int backward_core(vch2d_ctx *c, const double *phi_hist_dev, int M, const double *t_hist, double b1, double b2,
+                         const double *phiQ_dev, const double *phiT_dev, double *r_out, double *p_out, double *q_out) {
+    const long hs = hist_stride(c);
+    const Geom &G = c->G;
+    double *rhs = c->cphi, *Dn = c->cmu, *rcur = c->wnew;
+    double *qa = c->mu0, *qb = c->dmu;
+    // terminal condition (B2:183-187): (I - tau L) p_M = b2 (phi_M - phi_T), q_M = -L p_M, r_M = 0
+    LAUNCH(k_scaled_diff, c->grid, dim3(NTH), G, phi_hist_dev + (long)M * G.plane, hs, phiT_dev, G.plane, b2, rhs, c->part);
+    LAUNCH(k_adj_setup, c->grid, dim3(NTH), G, c->P, (const double *)nullptr, (const double *)rhs, Dn, c->part);
+    LAUNCH(k_fin_lin_begin, dim3(c->B), dim3(64), c->st, c->part, c->nblk, 0, c->P.tau, c->P.kappa, 0.0);
+    LAUNCH(k_fill, c->grid, dim3(NTH), G, c->x, 0.0);
+    VCHCHK(adjoint_solve_sweeps(c, 0.0, 3));
+    LAUNCH(k_adj_finish, c->grid, dim3(NTH), G, c->x, (const double *)nullptr, qa, rcur, 0.0, 0.0,
+           r_out ? r_out + (long)M * G.plane : (double *)nullptr, p_out ? p_out + (long)M * G.plane : (double *)nullptr,
+           q_out ? q_out + (long)M * G.plane : (double *)nullptr, hs);
+    for (int n = M - 1; n >= 0; --n) {
+        const double dtn = t_hist[n + 1] - t_hist[n];
+        double *rl = r_out ? r_out + (long)n * G.plane : nullptr;
+        double *pl = p_out ? p_out + (long)n * G.plane : nullptr;
+        double *ql = q_out ? q_out + (long)n * G.plane : nullptr;
+        if (dtn <= 1e-14) {       // B2:214-216: copy level n+1
+            if (rl) LAUNCH(k_copy_plane, c->grid, dim3(NTH), G, r_out + (long)(n + 1) * G.plane, hs, rl, hs);
+            if (pl) LAUNCH(k_copy_plane, c->grid, dim3(NTH), G, p_out + (long)(n + 1) * G.plane, hs, pl, hs);
+            if (ql) LAUNCH(k_copy_plane, c->grid, dim3(NTH), G, q_out + (long)(n + 1) * G.plane, hs, ql, hs);
+            continue;
+        }
+        LAUNCH(k_adj_rhs, c->grid, dim3(NTH), G, c->P, c->x, qa, phi_hist_dev + (long)n * G.plane,
+               phi_hist_dev + (long)(n + 1) * G.plane, phiQ_dev ? phiQ_dev + (long)n * G.plane : (const double *)nullptr,
+               phiQ_dev ? phiQ_dev + (long)(n + 1) * G.plane : (const double *)nullptr, hs, dtn, b1, rhs, Dn, c->part);
+        LAUNCH(k_fin_lin_begin, dim3(c->B), dim3(64), c->st, c->part, c->nblk, 0, c->P.tau, c->P.kappa, dtn);
+        VCHCHK(sync_state(c));
+        VCHCHK(adjoint_solve_sweeps(c, dtn, sweeps_for(c, false)));
+        const double den = c->P.gamma + 0.5 * dtn;
+        LAUNCH(k_adj_finish, c->grid, dim3(NTH), G, c->x, qa, qb, rcur, (c->P.gamma - 0.5 * dtn) / den, (0.5 * dtn) / den, rl,
+               pl, ql, hs);
+        std::swap(qa, qb);
+    }
+    return 0;
+}
+
+extern "C" int vch2d_backward(vch2d_ctx *c, const double *phi_hist, int M, const double *t_hist, double hx, double hy,
+                              double b1, double b2, const double *phi_Q, const double *phi_T, double *p_out, double *q_out,
+                              double *r_out, vch_stats *stats) {
+    CTXCHK(c);
+    ARGCHK(t_hist && M >= 1 && M <= c->Mmax, "NULL t_hist or M out of range");
+    // the reference takes hx, hy from x[1]-x[0], y[1]-y[0] (B2:154-155): must agree with the context's grid
+    ARGCHK(std::fabs(hx - c->hx) <= 1e-12 * c->hx && std::fabs(hy - c->hy) <= 1e-12 * c->hy,
+           "grid spacing differs from the context's Lx/Nx, Ly/Ny");
+    if (phi_hist) {
+        VCHCHK(ensure_hist(c, &c->phi_hist));
+        VCHCHK(h2d_hist(c, c->phi_hist, phi_hist, M + 1));
+        c->M_res = M;
+    } else {
+        if (c->M_res != M) return vch_fail(VCH_ERR_STATE, "vch2d_backward: no resident history with %d steps", M);
+    }
+    const double *pq = nullptr, *pt = nullptr;
+    if (phi_Q == VCH_RESIDENT) {
+        pq = c->phiQ;
+    } else if (phi_Q) {
+        VCHCHK(ensure_hist(c, &c->phiQ));
+        VCHCHK(h2d_hist(c, c->phiQ, phi_Q, M + 1));
+        pq = c->phiQ;
+    }
+    if (phi_T == VCH_RESIDENT) {
+        pt = c->phiT;
+    } else if (phi_T) {
+        VCHCHK(h2d(c, c->phiT, phi_T, c->B));
+        pt = c->phiT;
+    }
+    VCHCHK(ensure_hist(c, &c->r_hist));
+    if (p_out) VCHCHK(ensure_hist(c, &c->p_hist));
+    if (q_out) VCHCHK(ensure_hist(c, &c->q_hist));
+    VCHCHK(reset_counters(c));
+    HIPCHK(hipEventRecord(c->ev0, c->stream));
+    VCHCHK(backward_core(c, c->phi_hist, M, t_hist, b1, b2, pq, pt, c->r_hist, p_out ? c->p_hist : nullptr,
+                         q_out ? c->q_hist : nullptr));
+    HIPCHK(hipEventRecord(c->ev1, c->stream));
+    VCHCHK(sync_state(c));
+    if (r_out) VCHCHK(d2h_hist(c, r_out, c->r_hist, M + 1));
+    if (p_out) VCHCHK(d2h_hist(c, p_out, c->p_hist, M + 1));
+    if (q_out) VCHCHK(d2h_hist(c, q_out, c->q_hist, M + 1));
+    float ms = 0;
+    hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    fill_stats(c, stats, ms);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// cost (C2:80-108), gradient + prox (C2:150, C2:191-198)
+// ------------------------------------------------------------------------------------
+// trapezoid weights with np.trapz's arithmetic on the caller's grid: w_i = (d_{i-1} + d_i)/2
+static std::vector<double> trapz_w(const double *x, int n) {
+    std::vector<double> w(n, 0.0);
+    for (int i = 0; i + 1 < n; ++i) {
+        double d = x[i + 1] - x[i];
+        w[i] += 0.5 * d;
+        w[i + 1] += 0.5 * d;
+    }
+    return w;
+}
+
+static int set_cost_weights(vch2d_ctx *c, const double *x, const double *y) {
+    const Geom &G = c->G;
+    const int nx1 = c->prm.Nx + 1, ny1 = c->prm.Ny + 1;
+    std::vector<double> wx = trapz_w(x, nx1), wy = trapz_w(y, ny1), W((size_t)G.plane, 0.0);
+    for (int i = 0; i < nx1; ++i)
+        for (int j = 0; j < ny1; ++j) {
+            long f = (long)i * ny1 + j;
+            W[(f / G.nf) * G.pitch + (f % G.nf)] = wx[i] * wy[j];
+        }
+    HIPCHK(hipMemcpyAsync(c->W_cost, W.data(), W.size() * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// J_out [B][5]; arrays on the device in history layout; phiQ_dev NULL + ramp => on-the-fly ramp target
+static int cost_core(vch2d_ctx *c, const double *phi_dev, const double *u_dev, const double *pq_dev, const double *pt_dev,
+                     bool ramp, int M, const double *t_hist, const vch_opt_params *o, double *J_out) {
+    const Geom &G = c->G;
+    const int levels = M + 1, ntiles = c->nblk;
+    if (!c->cost_part) {
+        const size_t n = (size_t)c->B * (c->Mmax + 1) * ntiles * 4;
+        HIPCHK(hipMalloc((void **)&c->cost_part, n * 8));
+        HIPCHK(hipMalloc((void **)&c->cost_lvl, (size_t)c->B * (c->Mmax + 1) * 4 * 8));
+        HIPCHK(hipHostMalloc((void **)&c->cost_lvl_host, (size_t)c->B * (c->Mmax + 1) * 4 * 8));
+    }
+    dim3 g(ntiles, levels, c->B);
+    LAUNCH(k_cost, g, dim3(NTH), G, G.tiles_f, phi_dev, u_dev, pq_dev, pt_dev, (const double *)c->phi0,
+           (const double *)((ramp && !pq_dev) ? c->tfrac_dev : nullptr), hist_stride(c), M, (const double *)c->W_cost,
+           c->cost_part);
+    LAUNCH(k_cost_fin, dim3(c->B * levels), dim3(64), ntiles, (const double *)c->cost_part, c->cost_lvl);
+    HIPCHK(hipMemcpyAsync(c->cost_lvl_host, c->cost_lvl, (size_t)c->B * levels * 4 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int b = 0; b < c->B; ++b) {
+        const double *s = c->cost_lvl_host + (size_t)b * levels * 4;
+        double i1 = 0.0, i3 = 0.0, i4 = 0.0;
+        for (int n = 0; n < M; ++n) {          // np.trapz over t (C2:84,98,106)
+            const double d = t_hist[n + 1] - t_hist[n];
+            i1 += d * (s[(n + 1) * 4 + 0] + s[n * 4 + 0]) / 2.0;
+            i3 += d * (s[(n + 1) * 4 + 2] + s[n * 4 + 2]) / 2.0;
+            i4 += d * (s[(n + 1) * 4 + 3] + s[n * 4 + 3]) / 2.0;
+        }
+        double *J = J_out + 5 * b;
+        J[0] = (o->b1 / 2.0) * i1;
+        J[1] = (o->b2 / 2.0) * s[M * 4 + 1];
+        J[2] = (o->b3 / 2.0) * i3;
+        J[3] = o->kappa_sparsity * i4;
+        J[4] = J[0] + J[1] + J[2] + J[3];
+    }
+    return 0;
+}
+
+extern "C" int vch2d_cost(vch2d_ctx *c, const double *phi_hist, const double *u, const double *phi_Q, const double *phi_T,
+                          int M, const double *x, const double *y, const double *t_hist, const vch_opt_params *opt,
+                          double *J_out) {
+    CTXCHK(c);
+    ARGCHK(x && y && t_hist && opt && J_out && M >= 1 && M <= c->Mmax, "NULL argument or M out of range");
+    VCHCHK(set_cost_weights(c, x, y));
+    if (phi_hist) {
+        VCHCHK(ensure_hist(c, &c->phi_hist));
+        VCHCHK(h2d_hist(c, c->phi_hist, phi_hist, M + 1));
+        c->M_res = M;
+    } else if (c->M_res != M) {
+        return vch_fail(VCH_ERR_STATE, "vch2d_cost: no resident history with %d steps", M);
+    }
+    const double *ud = nullptr, *pq = nullptr, *pt = nullptr;
+    if (u == VCH_RESIDENT) {
+        ud = c->u_hist;
+    } else if (u) {
+        VCHCHK(ensure_hist(c, &c->u_hist));
+        VCHCHK(h2d_hist(c, c->u_hist, u, M + 1));
+        c->u_rows_res = M + 1;
+        ud = c->u_hist;
+    }
+    if (phi_Q == VCH_RESIDENT) {
+        pq = c->phiQ;
+    } else if (phi_Q) {
+        VCHCHK(ensure_hist(c, &c->phiQ));
+        VCHCHK(h2d_hist(c, c->phiQ, phi_Q, M + 1));
+        pq = c->phiQ;
+    }
+    if (phi_T == VCH_RESIDENT) {
+        pt = c->phiT;
+    } else if (phi_T) {
+        VCHCHK(h2d(c, c->phiT, phi_T, c->B));
+        pt = c->phiT;
+    }
+    return cost_core(c, c->phi_hist, ud, pq, pt, false, M, t_hist, opt, J_out);
+}
+
+// u_out = prox(u - alpha (r + b3 u)); change_out [B][2] = {sum (u+ - u)^2, sum u^2} or NULL
+static int grad_prox_core(vch2d_ctx *c, const double *u_dev, const double *r_dev, int rows, const double *alpha_host,
+                          const vch_opt_params *o, double *uout_dev, double *change_out) {
+    HIPCHK(hipMemcpyAsync(c->alpha_dev, alpha_host, sizeof(double) * c->B, hipMemcpyHostToDevice, c->stream));
+    if (!c->cost_part) {
+        const size_t n = (size_t)c->B * (c->Mmax + 1) * c->nblk * 4;
+        HIPCHK(hipMalloc((void **)&c->cost_part, n * 8));
+        HIPCHK(hipMalloc((void **)&c->cost_lvl, (size_t)c->B * (c->Mmax + 1) * 4 * 8));
+        HIPCHK(hipHostMalloc((void **)&c->cost_lvl_host, (size_t)c->B * (c->Mmax + 1) * 4 * 8));
+    }
+    dim3 g(c->nblk, rows, c->B);
+    HIPCHK(hipMemsetAsync(c->cost_part, 0, (size_t)c->B * rows * c->nblk * 4 * 8, c->stream));
+    LAUNCH(k_grad_prox, g, dim3(NTH), c->G, c->G.tiles_f, u_dev, r_dev, hist_stride(c), (const double *)c->alpha_dev, o->b3,
+           o->kappa_sparsity, o->u_min, o->u_max, uout_dev, c->cost_part);
+    if (change_out) {
+        LAUNCH(k_cost_fin, dim3(c->B * rows), dim3(64), c->nblk, (const double *)c->cost_part, c->cost_lvl);
+        HIPCHK(hipMemcpyAsync(c->cost_lvl_host, c->cost_lvl, (size_t)c->B * rows * 4 * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        for (int b = 0; b < c->B; ++b) {
+            double d = 0.0, n = 0.0;
+            for (int l = 0; l < rows; ++l) {
+                d += c->cost_lvl_host[((size_t)b * rows + l) * 4 + 0];
+                n += c->cost_lvl_host[((size_t)b * rows + l) * 4 + 1];
+            }
+            change_out[2 * b] = d;
+            change_out[2 * b + 1] = n;
+        }
+    }
+    return 0;
+}
+
+extern "C" int vch2d_grad_prox(vch2d_ctx *c, const double *u, const double *r, int rows, const double *alpha,
+                               const vch_opt_params *opt, double *u_out) {
+    CTXCHK(c);
+    ARGCHK(u && r && alpha && opt && u_out && rows >= 1 && rows <= c->Mmax + 1, "NULL argument or rows out of range");
+    VCHCHK(ensure_hist(c, &c->u_hist));
+    VCHCHK(ensure_hist(c, &c->r_hist));
+    VCHCHK(ensure_hist(c, &c->u_trial));
+    VCHCHK(h2d_hist(c, c->u_hist, u, rows));
+    VCHCHK(h2d_hist(c, c->r_hist, r, rows));
+    VCHCHK(grad_prox_core(c, c->u_hist, c->r_hist, rows, alpha, opt, c->u_trial, nullptr));
+    return d2h_hist(c, u_out, c->u_trial, rows);
+}
+
+// ------------------------------------------------------------------------------------
+// device-resident PGD loop (G2:291-382)
+// ------------------------------------------------------------------------------------
+static int copy_traj(vch2d_ctx *c, double *dst, const double *src, int b, int rows) {
+    const long hs = hist_stride(c);
+    HIPCHK(hipMemcpyAsync(dst + b * hs, src + b * hs, sizeof(double) * rows * c->G.plane, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+
+extern "C" int vch2d_pgd_init(vch2d_ctx *c, const double *phi0, const double *phi_T, const double *phi_Q, int ramp, double T,
+                              const double *t_hist, int M, const double *x, const double *y, const vch_opt_params *opt,
+                              double *J0_out) {
+    CTXCHK(c);
+    ARGCHK(phi0 && phi_T && t_hist && x && y && opt && M >= 1 && M <= c->Mmax, "NULL argument or M out of range");
+    c->opt = *opt;
+    c->t_hist.assign(t_hist, t_hist + M + 1);
+    c->dt.resize(M);
+    for (int n = 0; n < M; ++n) {
+        c->dt[n] = t_hist[n + 1] - t_hist[n];
+        ARGCHK(c->dt[n] > 0, "t_hist must be strictly increasing");
+    }
+    c->xg.assign(x, x + c->prm.Nx + 1);
+    c->yg.assign(y, y + c->prm.Ny + 1);
+    VCHCHK(set_cost_weights(c, x, y));
+    VCHCHK(ensure_hist(c, &c->phi_hist));
+    VCHCHK(ensure_hist(c, &c->phi_trial));
+    VCHCHK(ensure_hist(c, &c->u_hist));
+    VCHCHK(ensure_hist(c, &c->u_trial));
+    VCHCHK(ensure_hist(c, &c->r_hist));
+    VCHCHK(h2d(c, c->phi0, phi0, c->B));
+    VCHCHK(h2d(c, c->phiT, phi_T, c->B));
+    c->ramp = false;
+    if (phi_Q) {
+        VCHCHK(ensure_hist(c, &c->phiQ));
+        VCHCHK(h2d_hist(c, c->phiQ, phi_Q, M + 1));
+    } else if (ramp) {
+        c->ramp = true;
+        c->rampT = T;
+        c->tfrac.resize(M + 1);
+        for (int n = 0; n <= M; ++n) c->tfrac[n] = t_hist[n] / T;      // G2:221
+        if (!c->tfrac_dev) HIPCHK(hipMalloc((void **)&c->tfrac_dev, sizeof(double) * (c->Mmax + 1)));
+        HIPCHK(hipMemcpyAsync(c->tfrac_dev, c->tfrac.data(), sizeof(double) * (M + 1), hipMemcpyHostToDevice, c->stream));
+        // materialise phi_Q once on the device (the adjoint source reads it every step)
+        VCHCHK(ensure_hist(c, &c->phiQ));
+        LAUNCH(k_ramp, dim3(c->nblk, M + 1, c->B), dim3(NTH), c->G, c->G.tiles_f, (const double *)c->phi0,
+               (const double *)c->phiT, (const double *)c->tfrac_dev, hist_stride(c), c->phiQ);
+    } else {
+        if (c->phiQ) HIPCHK(hipMemsetAsync(c->phiQ, 0, sizeof(double) * c->B * hist_stride(c), c->stream));
+    }
+    // u^0 = 0, uncontrolled march, J(u^0)   (G2:255-258, G2:291)
+    HIPCHK(hipMemsetAsync(c->u_hist, 0, sizeof(double) * c->B * hist_stride(c), c->stream));
+    c->u_rows_res = M + 1;
+    VCHCHK(reset_counters(c));
+    HIPCHK(hipMemcpyAsync(c->phi_s, c->phi0, sizeof(double) * c->B * c->G.plane, hipMemcpyDeviceToDevice, c->stream));
+    VCHCHK(forward_core(c, nullptr, 0, c->dt.data(), M, c->phi_hist));
+    c->M_res = M;
+    c->pgd_J.assign(5 * c->B, 0.0);
+    VCHCHK(cost_core(c, c->phi_hist, c->u_hist, (phi_Q || ramp) ? c->phiQ : nullptr, c->phiT, false, M, c->t_hist.data(),
+                     &c->opt, c->pgd_J.data()));
+    c->pgd_cost.resize(c->B);
+    c->pgd_alpha_prev.assign(c->B, opt->alpha_max);
+    c->pgd_plateau.assign(c->B, 0);
+    c->pgd_done.assign(c->B, 0);
+    c->pgd_k.assign(c->B, 0);
+    c->pgd_cost_hist.assign(c->B, {});
+    for (int b = 0; b < c->B; ++b) {
+        c->pgd_cost[b] = c->pgd_J[5 * b + 4];
+        c->pgd_cost_hist[b].push_back(c->pgd_cost[b]);
+    }
+    HIPCHK(hipMemcpyAsync(c->J_dev, c->pgd_J.data(), sizeof(double) * 5 * c->B, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (J0_out) memcpy(J0_out, c->pgd_J.data(), sizeof(double) * 5 * c->B);
+    c->pgd_ready = true;
+    return 0;
+}
+
+static double elapsed_s(vch2d_ctx *c, hipEvent_t a, hipEvent_t b) {
+    float ms = 0;
+    hipEventSynchronize(b);
+    hipEventElapsedTime(&ms, a, b);
+    return ms * 1e-3;
+}
+
+extern "C" int vch2d_pgd_iterate(vch2d_ctx *c, int n_iters, double *cost_out, double *alpha_out, int32_t *attempts_out,
+                                 double *change_out, double *seconds_out) {
+    CTXCHK(c);
+    if (!c->pgd_ready) return vch_fail(VCH_ERR_STATE, "vch2d_pgd_iterate: call vch2d_pgd_init first");
+    ARGCHK(n_iters >= 1, "n_iters must be >= 1");
+    const int B = c->B, M = c->M_res, rows = M + 1;
+    const double *pq = (c->phiQ) ? c->phiQ : nullptr;
+    double sec[5] = {0, 0, 0, 0, 0};
+    hipEvent_t e0 = c->ev0, e1 = c->ev1;
+    std::vector<double> alpha(B), Jt(5 * B), chg(2 * B), alpha_k(B), cost_new(B);
+    std::vector<int> attempts(B), accepted(B);
+    int done_iters = 0;
+    for (int it = 0; it < n_iters; ++it) {
+        bool all_done = true;
+        for (int b = 0; b < B; ++b) all_done &= (c->pgd_done[b] != 0);
+        if (all_done) break;
+        // --- adjoint sweep on the current state (G2:299)
+        HIPCHK(hipEventRecord(e0, c->stream));
+        VCHCHK(backward_core(c, c->phi_hist, M, c->t_hist.data(), c->opt.b1, c->opt.b2, pq, c->phiT, c->r_hist, nullptr, nullptr));
+        HIPCHK(hipEventRecord(e1, c->stream));
+        sec[0] += elapsed_s(c, e0, e1);
+        // --- optimistic step with alpha_prev (G2:304-313)
+        for (int b = 0; b < B; ++b) {
+            alpha[b] = c->pgd_alpha_prev[b];
+            attempts[b] = 0;
+            accepted[b] = c->pgd_done[b] ? 1 : 0;
+        }
+        for (int round = 0; round <= 10; ++round) {
+            // round 0 = optimistic step; rounds 1..10 = backtracking trials (G2:128-146)
+            HIPCHK(hipEventRecord(e0, c->stream));
+            VCHCHK(grad_prox_core(c, c->u_hist, c->r_hist, rows, alpha.data(), &c->opt, c->u_trial, chg.data()));
+            HIPCHK(hipEventRecord(e1, c->stream));
+            sec[1] += elapsed_s(c, e0, e1);
+            HIPCHK(hipEventRecord(e0, c->stream));
+            HIPCHK(hipMemcpyAsync(c->phi_s, c->phi0, sizeof(double) * B * c->G.plane, hipMemcpyDeviceToDevice, c->stream));
+            VCHCHK(reset_counters(c));
+            VCHCHK(forward_core(c, c->u_trial, rows, c->dt.data(), M, c->phi_trial));
+            HIPCHK(hipEventRecord(e1, c->stream));
+            sec[round == 0 ? 2 : 4] += elapsed_s(c, e0, e1);
+            HIPCHK(hipEventRecord(e0, c->stream));
+            VCHCHK(cost_core(c, c->phi_trial, c->u_trial, pq, c->phiT, false, M, c->t_hist.data(), &c->opt, Jt.data()));
+            HIPCHK(hipEventRecord(e1, c->stream));
+            sec[round == 0 ? 3 : 4] += elapsed_s(c, e0, e1);
+            bool pending = false;
+            for (int b = 0; b < B; ++b) {
+                if (accepted[b]) continue;
+                if (round > 0) attempts[b]++;
+                const bool ok = Jt[5 * b + 4] < c->pgd_cost[b];
+                const bool last = (round == 10);
+                if (ok || last) {
+                    // accept (or "return last try", G2:144-146, where alpha has been multiplied once more)
+                    accepted[b] = 1;
+                    alpha_k[b] = (ok ? alpha[b] : alpha[b] * 0.8);
+                    cost_new[b] = Jt[5 * b + 4];
+                    if (change_out) change_out[(long)b * n_iters + it] = std::sqrt(chg[2 * b]) / (std::sqrt(chg[2 * b + 1]) + 1e-9);
+                    c->pgd_J[5 * b + 0] = Jt[5 * b + 0]; c->pgd_J[5 * b + 1] = Jt[5 * b + 1];
+                    c->pgd_J[5 * b + 2] = Jt[5 * b + 2]; c->pgd_J[5 * b + 3] = Jt[5 * b + 3];
+                    c->pgd_J[5 * b + 4] = Jt[5 * b + 4];
+                    // the stop rule uses the relative control change (G2:375-381)
+                    const double change = std::sqrt(chg[2 * b]) / (std::sqrt(chg[2 * b + 1]) + 1e-9);
+                    VCHCHK(copy_traj(c, c->u_hist, c->u_trial, b, rows));
+                    VCHCHK(copy_traj(c, c->phi_hist, c->phi_trial, b, rows));
+                    c->pgd_cost_hist[b].push_back(cost_new[b]);
+                    auto &ch = c->pgd_cost_hist[b];
+                    const int k = c->pgd_k[b];
+                    if (k > 0 && std::fabs(ch[ch.size() - 1] - ch[ch.size() - 2]) < 1e-5) c->pgd_plateau[b]++;
+                    else c->pgd_plateau[b] = 0;
+                    if (c->pgd_plateau[b] >= 5) {
+                        c->pgd_alpha_prev[b] = std::min(c->opt.alpha_max, alpha_k[b] * 1.5);
+                        c->pgd_plateau[b] = 0;
+                    } else {
+                        c->pgd_alpha_prev[b] = std::min(c->opt.alpha_max, alpha_k[b] * 1.2);
+                    }
+                    if (change < 1e-5 && k > 20) c->pgd_done[b] = 1;
+                    c->pgd_cost[b] = cost_new[b];
+                    c->pgd_k[b] = k + 1;
+                    if (cost_out) cost_out[(long)b * n_iters + it] = cost_new[b];
+                    if (alpha_out) alpha_out[(long)b * n_iters + it] = alpha_k[b];
+                    if (attempts_out) attempts_out[(long)b * n_iters + it] = attempts[b];
+                } else {
+                    pending = true;
+                    alpha[b] = (round == 0) ? c->pgd_alpha_prev[b] * 0.8 : alpha[b] * 0.8;
+                }
+            }
+            if (!pending) break;
+        }
+        done_iters = it + 1;
+    }
+    HIPCHK(hipMemcpyAsync(c->J_dev, c->pgd_J.data(), sizeof(double) * 5 * B, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (seconds_out) memcpy(seconds_out, sec, sizeof(sec));
+    return done_iters;
+}
+
+extern "C" int vch2d_pgd_get(vch2d_ctx *c, int what, double *out) {
+    CTXCHK(c);
+    ARGCHK(out && what >= 0 && what <= 3, "NULL out or what not in 0..3");
+    if (!c->pgd_ready) return vch_fail(VCH_ERR_STATE, "vch2d_pgd_get: call vch2d_pgd_init first");
+    const double *src = what == 0 ? c->u_hist : what == 1 ? c->phi_hist : what == 2 ? c->r_hist : c->phiQ;
+    if (!src) return vch_fail(VCH_ERR_STATE, "vch2d_pgd_get: array %d is not resident", what);
+    return d2h_hist(c, out, src, c->M_res + 1);
+}
+
+extern "C" int vch2d_pgd_cost_dev(vch2d_ctx *c, double **ptr_dev) {
+    CTXCHK(c);
+    ARGCHK(ptr_dev, "NULL ptr_dev");
+    if (!c->pgd_ready) return vch_fail(VCH_ERR_STATE, "vch2d_pgd_cost_dev: call vch2d_pgd_init first");
+    *ptr_dev = c->J_dev;
+    return 0;
+}

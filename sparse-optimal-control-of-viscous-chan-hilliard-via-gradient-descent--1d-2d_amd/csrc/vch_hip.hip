@@ -1,0 +1,2 @@
+// vch_hip.hip — single translation unit of libvch_hip.so (gfx950).
+#include "vch_engine2d.hip"

@@ -1,0 +1,1065 @@
+// vch_kernels2d.h — hand-written HIP kernels of the 2D hot path (gfx950, wave64, fp64).
+//
+// All kernels are batched over B independent trajectories (blockIdx.z) and work on
+// TX x TY tiles of one padded plane, staged through LDS with a mirrored (reflect) halo so
+// that the Neumann boundary rows need no branches: the mirrored ghost v[-1] = v[1]
+// reproduces the doubled off-diagonals of the reference's Laplacian (F2:119-121), and
+// applying the same rule twice reproduces its L@L (B2:159).
+//
+// Per-trajectory control flow (Newton convergence, Armijo acceptance, linear-solver
+// convergence) lives in a small TrajState record in device memory; stencil kernels read
+// it and return early for trajectories that are not in the corresponding phase, tiny
+// `fin` kernels (one workgroup per trajectory) update it from per-workgroup partials in a
+// fixed order, so results are deterministic run to run.
+#pragma once
+#include "vch_common.h"
+
+struct TrajState {
+    // Newton iteration (F2:323-427)
+    int slot;            // which of the two iterate buffers holds (phi+, mu+, R_phi, rhs, D)
+    int newton_active;   // Newton loop still running for this trajectory
+    int need_trial;      // an Armijo trial (or the initial residual) is pending
+    int trial_no;        // halvings done in the current Armijo loop
+    int force_accept;    // take the pending trial unconditionally (best-trial fallback F2:420-423)
+    int iters;           // residual norms recorded (= len(hist))
+    int nsolves;         // linear solves started
+    int ntrials;         // Armijo residual evaluations
+    int stuck;           // 12 trials failed and no trial improved: state can never change again
+    int pad0;
+    double normR;        // ||[R_phi;R_mu]||_2 of the current iterate
+    double alpha;        // step of the pending trial
+    double best_norm, best_alpha;
+    double Dmin, Dmax, dbar;   // range of the Jacobian diagonal, preconditioner shift
+    double rho, theta;         // contraction bound of the Richardson sweep, stagnation threshold
+    long newton_total;         // residual norms recorded over the whole march
+    // linear solve (preconditioned Richardson on the Schur system)
+    int lin_active, lin_it;
+    long lin_total;
+    double lin_r0, lin_prev, lin_rel, lin_maxrel;
+    // mass fix (F2:565-577)
+    double mass0, mass_err, Wint;
+    // scratch for cost / change norms
+    double aux[4];
+};
+
+struct Phys {
+    double tau, gamma, c1, c2, kappa;
+    double LxLy;
+};
+
+// ---------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ int refl(int i, int n) {
+    i = i < 0 ? -i : i;
+    i = i >= n ? 2 * (n - 1) - i : i;
+    return i < 0 ? 0 : i;
+}
+
+template <int H>
+__device__ __forceinline__ void load_tile(double *s, const double *__restrict__ g, const Geom &G,
+                                          int c0, int r0) {
+    constexpr int W = TX + 2 * H, HT = TY + 2 * H;
+    for (int e = threadIdx.x; e < W * HT; e += NTH) {
+        int ly = e / W, lx = e - ly * W;
+        int gr = refl(r0 - H + ly, G.ns), gc = refl(c0 - H + lx, G.nf);
+        s[e] = g[(long)gr * G.pitch + gc];
+    }
+}
+
+// s = a + alpha * d on the haloed tile
+template <int H>
+__device__ __forceinline__ void load_tile_axpy(double *s, const double *__restrict__ a,
+                                               const double *__restrict__ d, double alpha,
+                                               const Geom &G, int c0, int r0) {
+    constexpr int W = TX + 2 * H, HT = TY + 2 * H;
+    for (int e = threadIdx.x; e < W * HT; e += NTH) {
+        int ly = e / W, lx = e - ly * W;
+        int gr = refl(r0 - H + ly, G.ns), gc = refl(c0 - H + lx, G.nf);
+        long o = (long)gr * G.pitch + gc;
+        s[e] = a[o] + alpha * d[o];
+    }
+}
+
+// 5-point mirrored-Neumann Laplacian at LDS position p of a tile with row stride W
+template <int W>
+__device__ __forceinline__ double lap_at(const double *s, int p, double ax, double ay) {
+    double c = s[p];
+    return ax * ((s[p - 1] + s[p + 1]) - 2.0 * c) + ay * ((s[p - W] + s[p + W]) - 2.0 * c);
+}
+
+__device__ __forceinline__ double reglog(double phi) {   // F2:86-102 with delta_sep = 1e-2
+    const double eps = 0.5 * DELTA_SEP;                  // max(1e-8, delta_sep/2)
+    double p = fmin(fmax(phi, -1.0 + eps), 1.0 - eps);
+    return log((1.0 + p) / (1.0 - p));
+}
+
+__device__ __forceinline__ double jac_diag(double phi, double tau_dt, double c1) {   // F2:243-244
+    double psq = fmin(fmax(phi * phi, 0.0), 1.0 - DELTA_SEP * DELTA_SEP);
+    return tau_dt + 2.0 * c1 / (1.0 - psq);
+}
+
+__device__ __forceinline__ double fpp_log(double phi, double c1, double c2) {   // B2:71-72
+    double p = fmin(fmax(phi, -1.0 + 1e-8), 1.0 - 1e-8);
+    return 2.0 * c1 / (1.0 - p * p) - 2.0 * c2;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_down(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+    return v;
+}
+
+// Workgroup reduction of up to NPART values per thread (op: 0 sum, 1 min, 2 max); thread 0
+// writes the results to part[0..n).  sred must hold NPART*4 doubles.
+template <int N>
+__device__ __forceinline__ void block_reduce_store(double (&v)[N], const int (&op)[N], double *sred,
+                                                   double *part) {
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        double r = op[k] == 0 ? wave_sum(v[k]) : (op[k] == 1 ? wave_min(v[k]) : wave_max(v[k]));
+        if (lane == 0) sred[k * 4 + wv] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            double a = sred[k * 4], b = sred[k * 4 + 1], c = sred[k * 4 + 2], d = sred[k * 4 + 3];
+            part[k] = op[k] == 0 ? (a + b) + (c + d)
+                                 : (op[k] == 1 ? fmin(fmin(a, b), fmin(c, d)) : fmax(fmax(a, b), fmax(c, d)));
+        }
+    }
+}
+
+#define TILE_COORDS                                   \
+    const int b = blockIdx.z;                         \
+    const int c0 = blockIdx.x * TX, r0 = blockIdx.y * TY; \
+    const int lx = threadIdx.x & 63, ly0 = threadIdx.x >> 6; \
+    const int blk = blockIdx.y * gridDim.x + blockIdx.x;  \
+    const int nblk = gridDim.x * gridDim.y;           \
+    (void)blk; (void)nblk; (void)lx; (void)ly0
+
+// ---------------------------------------------------------------------------------
+// out = L v                                                  (apply_laplacian, F2:140-152)
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTH) void k_lap(Geom G, const double *__restrict__ v, double *__restrict__ out) {
+    TILE_COORDS;
+    __shared__ double s[(TY + 2) * (TX + 2)];
+    constexpr int W = TX + 2;
+    load_tile<1>(s, v + b * G.plane, G, c0, r0);
+    __syncthreads();
+    for (int k = 0; k < TY / 4; ++k) {
+        int ly = ly0 + 4 * k, r = r0 + ly, c = c0 + lx;
+        if (r < G.ns && c < G.nf)
+            out[b * G.plane + (long)r * G.pitch + c] = lap_at<W>(s, (ly + 1) * W + lx + 1, G.ax, G.ay);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// mu = -kappa L phi + c1 reglog(phi) - 2 c2 phi - w           (initialize_mu, F2:155-167)
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTH) void k_init_mu(Geom G, Phys P, const double *__restrict__ phi,
+                                                 const double *__restrict__ w, double *__restrict__ mu) {
+    TILE_COORDS;
+    __shared__ double s[(TY + 2) * (TX + 2)];
+    constexpr int W = TX + 2;
+    load_tile<1>(s, phi + b * G.plane, G, c0, r0);
+    __syncthreads();
+    for (int k = 0; k < TY / 4; ++k) {
+        int ly = ly0 + 4 * k, r = r0 + ly, c = c0 + lx;
+        if (r < G.ns && c < G.nf) {
+            int p = (ly + 1) * W + lx + 1;
+            long o = b * G.plane + (long)r * G.pitch + c;
+            double ph = s[p];
+            mu[o] = -P.kappa * lap_at<W>(s, p, G.ax, G.ay) + (P.c1 * reglog(ph) - 2.0 * P.c2 * ph) - w[o];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Start of a time step (F2:545-551, F2:350-351).  From the old level (phi, mu, w) and the
+// control rows u_n, u_{n+1} (NULL = zeros) form
+//   w_new = ((g-1/2) w + (u_n+u_{n+1})/2)/(g+1/2), g = gamma/dt          (solve_w, F2:180-181)
+//   mu0   = -kappa L phi + c1 reglog(phi) - 2 c2 phi - w_new            (Newton initial guess)
+//   c_phi = -(tau/dt) phi - kappa/2 L phi - 2 c2 phi - mu/2 - (w_new + w)/2   old-level part of R_phi
+//   c_mu  = -phi/dt - L mu / 2                                                 old-level part of R_mu
+// (wnew_in != NULL: w_new is given, as in a bare newton_raphson call, F2:323)
+// so that R_phi = (tau/dt) phi+ - kappa/2 L phi+ + c1 reglog(phi+) - mu+/2 + c_phi and
+// R_mu = phi+/dt - L mu+/2 + c_mu (F2:194-221 with the old-level terms pre-combined).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTH) void k_prepare(Geom G, Phys P, const TrajState *__restrict__ st,
+                                                 long slot_stride, const double *__restrict__ phi_s,
+                                                 const double *__restrict__ mu_s, const double *__restrict__ w,
+                                                 const double *__restrict__ un, const double *__restrict__ unp1,
+                                                 long u_stride, const double *__restrict__ wnew_in, double dt,
+                                                 double *__restrict__ wnew,
+                                                 double *__restrict__ mu0, double *__restrict__ cphi,
+                                                 double *__restrict__ cmu) {
+    TILE_COORDS;
+    __shared__ double sp[(TY + 2) * (TX + 2)];
+    __shared__ double sm[(TY + 2) * (TX + 2)];
+    constexpr int W = TX + 2;
+    const int slot = st[b].slot;
+    load_tile<1>(sp, phi_s + slot * slot_stride + b * G.plane, G, c0, r0);
+    load_tile<1>(sm, mu_s + slot * slot_stride + b * G.plane, G, c0, r0);
+    __syncthreads();
+    const double gdt = P.gamma / dt;
+    for (int k = 0; k < TY / 4; ++k) {
+        int ly = ly0 + 4 * k, r = r0 + ly, c = c0 + lx;
+        if (r < G.ns && c < G.nf) {
+            int p = (ly + 1) * W + lx + 1;
+            long o = (long)r * G.pitch + c;
+            long ob = b * G.plane + o;
+            double u0 = un ? un[b * u_stride + o] : 0.0, u1 = unp1 ? unp1[b * u_stride + o] : 0.0;
+            double wo = w[ob];
+            double wn = wnew_in ? wnew_in[ob] : ((gdt - 0.5) * wo + 0.5 * (u1 + u0)) / (gdt + 0.5);
+            double ph = sp[p], lp = lap_at<W>(sp, p, G.ax, G.ay), lm = lap_at<W>(sm, p, G.ax, G.ay);
+            wnew[ob] = wn;
+            mu0[ob] = -P.kappa * lp + (P.c1 * reglog(ph) - 2.0 * P.c2 * ph) - wn;
+            cphi[ob] = -(P.tau / dt) * ph - 0.5 * P.kappa * lp - 2.0 * P.c2 * ph - 0.5 * sm[p] - 0.5 * (wn + wo);
+            cmu[ob] = -ph / dt - 0.5 * lm;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Residual of a Newton iterate / Armijo trial (F2:357-360, F2:399-408), fused with
+// everything the next linear solve needs:
+//   MODE 0 (initial residual): iterate = (phi[slot], mu0)      -> written to slot `slot`
+//   MODE 1 (trial):            iterate = (phi, mu)[slot] + alpha (dphi, dmu) -> slot 1-slot
+// Outputs per node: phi_t, mu_t, R_phi, D = tau/dt + 2c1/(1-clip(phi_t^2)) (F2:243-244) and
+// the Schur right-hand side rhs = -R_mu + L R_phi; per workgroup: sum(R_phi^2 + R_mu^2),
+// sum(rhs^2), min D, max D.
+// ---------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(NTH) void k_residual(Geom G, Phys P, const TrajState *__restrict__ st,
+                                                  long slot_stride, double *__restrict__ phi_s,
+                                                  double *__restrict__ mu_s, double *__restrict__ Rphi_s,
+                                                  double *__restrict__ rhs_s, double *__restrict__ D_s,
+                                                  const double *__restrict__ mu0, const double *__restrict__ dphi,
+                                                  const double *__restrict__ dmu, const double *__restrict__ cphi,
+                                                  const double *__restrict__ cmu, double dt,
+                                                  double *__restrict__ part) {
+    TILE_COORDS;
+    const TrajState S = st[b];
+    if (!S.newton_active || !S.need_trial) return;
+    __shared__ double sp[(TY + 4) * (TX + 4)];
+    __shared__ double sm[(TY + 2) * (TX + 2)];
+    __shared__ double sr[(TY + 2) * (TX + 2)];
+    __shared__ double sred[NPART * 4];
+    constexpr int W2 = TX + 4, W1 = TX + 2;
+    const long pb = b * G.plane;
+    const int src = S.slot, dst = MODE == 0 ? S.slot : 1 - S.slot;
+    if (MODE == 0) {
+        load_tile<2>(sp, phi_s + src * slot_stride + pb, G, c0, r0);
+        load_tile<1>(sm, mu0 + pb, G, c0, r0);
+    } else {
+        load_tile_axpy<2>(sp, phi_s + src * slot_stride + pb, dphi + pb, S.alpha, G, c0, r0);
+        load_tile_axpy<1>(sm, mu_s + src * slot_stride + pb, dmu + pb, S.alpha, G, c0, r0);
+    }
+    __syncthreads();
+    const double tdt = P.tau / dt;
+    // R_phi on the tile + halo 1
+    for (int e = threadIdx.x; e < (TY + 2) * W1; e += NTH) {
+        int ly = e / W1, lxx = e - ly * W1;
+        int gr = refl(r0 - 1 + ly, G.ns), gc = refl(c0 - 1 + lxx, G.nf);
+        int p2 = (ly + 1) * W2 + lxx + 1;
+        double ph = sp[p2];
+        sr[e] = tdt * ph - 0.5 * P.kappa * lap_at<W2>(sp, p2, G.ax, G.ay) + P.c1 * reglog(ph) - 0.5 * sm[e] +
+                cphi[pb + (long)gr * G.pitch + gc];
+    }
+    __syncthreads();
+    double acc[4] = {0.0, 0.0, 1e300, -1e300};
+    for (int k = 0; k < TY / 4; ++k) {
+        int ly = ly0 + 4 * k, r = r0 + ly, c = c0 + lx;
+        if (r < G.ns && c < G.nf) {
+            int p1 = (ly + 1) * W1 + lx + 1, p2 = (ly + 2) * W2 + lx + 2;
+            long o = pb + (long)r * G.pitch + c;
+            double ph = sp[p2], rp = sr[p1];
+            double rm = ph / dt - 0.5 * lap_at<W1>(sm, p1, G.ax, G.ay) + cmu[o];
+            double rh = -rm + lap_at<W1>(sr, p1, G.ax, G.ay);
+            double d = jac_diag(ph, tdt, P.c1);
+            long od = dst * slot_stride + o;
+            if (MODE == 1) phi_s[od] = ph;
+            mu_s[od] = sm[p1];
+            Rphi_s[od] = rp;
+            rhs_s[od] = rh;
+            D_s[od] = d;
+            acc[0] += rp * rp + rm * rm;
+            acc[1] += rh * rh;
+            acc[2] = fmin(acc[2], d);
+            acc[3] = fmax(acc[3], d);
+        }
+    }
+    const int op[4] = {0, 0, 1, 2};
+    block_reduce_store<4>(acc, op, sred, part + ((long)b * nblk + blk) * NPART);
+}
+
+// ---------------------------------------------------------------------------------
+// Schur-reduced Newton operator  A x = x/dt + M (kappa/2 M x + D x),  M = -L   (13-point).
+//   MODE 0: out = A x                      (vch2d_schur_apply)
+//   MODE 1: out = rhs[slot] - A x, + sum(out^2) per workgroup   (Richardson residual)
+// This is the "Newton stencil SpMV" of the north star: algorithmic traffic per node is
+// x, D, rhs in and r out = 32 B (24 B in MODE 0).
+// ---------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(NTH) void k_schur(Geom G, Phys P, const TrajState *__restrict__ st,
+                                               long slot_stride, const double *__restrict__ x,
+                                               const double *__restrict__ D_s, const double *__restrict__ rhs_s,
+                                               double dt, double *__restrict__ out, double *__restrict__ part) {
+    TILE_COORDS;
+    int slot = 0;
+    if (MODE == 1) {
+        const TrajState S = st[b];
+        if (!S.lin_active) return;
+        slot = S.slot;
+    } else if (st) {
+        slot = st[b].slot;
+    }
+    __shared__ double sx[(TY + 4) * (TX + 4)];
+    __shared__ double stt[(TY + 2) * (TX + 2)];
+    __shared__ double sred[NPART * 4];
+    constexpr int W2 = TX + 4, W1 = TX + 2;
+    const long pb = b * G.plane;
+    load_tile<2>(sx, x + pb, G, c0, r0);
+    __syncthreads();
+    const double *Dp = D_s + slot * slot_stride + pb;
+    for (int e = threadIdx.x; e < (TY + 2) * W1; e += NTH) {
+        int ly = e / W1, lxx = e - ly * W1;
+        int gr = refl(r0 - 1 + ly, G.ns), gc = refl(c0 - 1 + lxx, G.nf);
+        int p2 = (ly + 1) * W2 + lxx + 1;
+        stt[e] = -0.5 * P.kappa * lap_at<W2>(sx, p2, G.ax, G.ay) + Dp[(long)gr * G.pitch + gc] * sx[p2];
+    }
+    __syncthreads();
+    double acc[1] = {0.0};
+    const double idt = 1.0 / dt;
+    for (int k = 0; k < TY / 4; ++k) {
+        int ly = ly0 + 4 * k, r = r0 + ly, c = c0 + lx;
+        if (r < G.ns && c < G.nf) {
+            int p1 = (ly + 1) * W1 + lx + 1, p2 = (ly + 2) * W2 + lx + 2;
+            long o = pb + (long)r * G.pitch + c;
+            double ax_ = sx[p2] * idt - lap_at<W1>(stt, p1, G.ax, G.ay);
+            if (MODE == 0) {
+                out[o] = ax_;
+            } else {
+                double rr = rhs_s[slot * slot_stride + o] - ax_;
+                out[o] = rr;
+                acc[0] += rr * rr;
+            }
+        }
+    }
+    if (MODE == 1) {
+        const int op[1] = {0};
+        block_reduce_store<1>(acc, op, sred, part + ((long)b * nblk + blk) * NPART);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// After the linear solve: dphi = x; dmu = 2 (K dphi + R_phi), K = kappa/2 M + D (back
+// substitution of the Schur reduction); per workgroup min over nodes of the step-ceiling
+// ratio ((+-(1-delta) - phi)/dphi, F2:381-387).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTH) void k_dmu_ceiling(Geom G, Phys P, const TrajState *__restrict__ st,
+                                                     long slot_stride, const double *__restrict__ x,
+                                                     const double *__restrict__ phi_s,
+                                                     const double *__restrict__ D_s,
+                                                     const double *__restrict__ Rphi_s, double *__restrict__ dmu,
+                                                     double *__restrict__ part) {
+    TILE_COORDS;
+    const TrajState S = st[b];
+    if (!S.newton_active || S.need_trial) return;
+    __shared__ double sx[(TY + 2) * (TX + 2)];
+    __shared__ double sred[NPART * 4];
+    constexpr int W = TX + 2;
+    const long pb = b * G.plane;
+    load_tile<1>(sx, x + pb, G, c0, r0);
+    __syncthreads();
+    double acc[1] = {1e300};
+    for (int k = 0; k < TY / 4; ++k) {
+        int ly = ly0 + 4 * k, r = r0 + ly, c = c0 + lx;
+        if (r < G.ns && c < G.nf) {
+            int p = (ly + 1) * W + lx + 1;
+            long o = pb + (long)r * G.pitch + c, os = S.slot * slot_stride + o;
+            double d = sx[p];
+            dmu[o] = 2.0 * ((-0.5 * P.kappa * lap_at<W>(sx, p, G.ax, G.ay) + D_s[os] * d) + Rphi_s[os]);
+            double ph = phi_s[os];
+            if (d > 0.0) acc[0] = fmin(acc[0], (1.0 - DELTA_SEP - ph) / d);
+            else if (d < 0.0) acc[0] = fmin(acc[0], (-1.0 + DELTA_SEP - ph) / d);
+        }
+    }
+    const int op[1] = {1};
+    block_reduce_store<1>(acc, op, sred, part + ((long)b * nblk + blk) * NPART);
+}
+
+// (out_phi, out_mu) = J [dphi; dmu]  (F2:241-253), for the kernel-level parity test.
+__global__ __launch_bounds__(NTH) void k_jac_apply(Geom G, Phys P, const double *__restrict__ phi,
+                                                   const double *__restrict__ dphi, const double *__restrict__ dmu,
+                                                   double dt, double *__restrict__ op_, double *__restrict__ om_) {
+    TILE_COORDS;
+    __shared__ double sa[(TY + 2) * (TX + 2)];
+    __shared__ double sb[(TY + 2) * (TX + 2)];
+    constexpr int W = TX + 2;
+    const long pb = b * G.plane;
+    load_tile<1>(sa, dphi + pb, G, c0, r0);
+    load_tile<1>(sb, dmu + pb, G, c0, r0);
+    __syncthreads();
+    for (int k = 0; k < TY / 4; ++k) {
+        int ly = ly0 + 4 * k, r = r0 + ly, c = c0 + lx;
+        if (r < G.ns && c < G.nf) {
+            int p = (ly + 1) * W + lx + 1;
+            long o = pb + (long)r * G.pitch + c;
+            double d = jac_diag(phi[o], P.tau / dt, P.c1);
+            op_[o] = -0.5 * P.kappa * lap_at<W>(sa, p, G.ax, G.ay) + d * sa[p] - 0.5 * sb[p];
+            om_[o] = sa[p] / dt - 0.5 * lap_at<W>(sb, p, G.ax, G.ay);
+        }
+    }
+}
+
+// Stand-alone (R_phi, R_mu) in the reference's own form (F2:194-221), for the parity test.
+__global__ __launch_bounds__(NTH) void k_residual_plain(Geom G, Phys P, const double *__restrict__ pn,
+                                                        const double *__restrict__ po, const double *__restrict__ mn,
+                                                        const double *__restrict__ mo, const double *__restrict__ wn,
+                                                        const double *__restrict__ wo, double dt,
+                                                        double *__restrict__ Rp, double *__restrict__ Rm,
+                                                        double *__restrict__ part) {
+    TILE_COORDS;
+    __shared__ double s[4][(TY + 2) * (TX + 2)];
+    __shared__ double sred[NPART * 4];
+    constexpr int W = TX + 2;
+    const long pb = b * G.plane;
+    load_tile<1>(s[0], pn + pb, G, c0, r0);
+    load_tile<1>(s[1], po + pb, G, c0, r0);
+    load_tile<1>(s[2], mn + pb, G, c0, r0);
+    load_tile<1>(s[3], mo + pb, G, c0, r0);
+    __syncthreads();
+    double acc[1] = {0.0};
+    for (int k = 0; k < TY / 4; ++k) {
+        int ly = ly0 + 4 * k, r = r0 + ly, c = c0 + lx;
+        if (r < G.ns && c < G.nf) {
+            int p = (ly + 1) * W + lx + 1;
+            long o = pb + (long)r * G.pitch + c;
+            double rp = (P.tau * (s[0][p] - s[1][p]) / dt) -
+                        0.5 * P.kappa * (lap_at<W>(s[0], p, G.ax, G.ay) + lap_at<W>(s[1], p, G.ax, G.ay)) +
+                        (P.c1 * reglog(s[0][p]) + (-2.0 * P.c2 * s[1][p])) - 0.5 * (s[2][p] + s[3][p]) -
+                        0.5 * (wn[o] + wo[o]);
+            double rm = (s[0][p] - s[1][p]) / dt - 0.5 * (lap_at<W>(s[2], p, G.ax, G.ay) + lap_at<W>(s[3], p, G.ax, G.ay));
+            Rp[o] = rp;
+            Rm[o] = rm;
+            acc[0] += rp * rp + rm * rm;
+        }
+    }
+    const int op[1] = {0};
+    block_reduce_store<1>(acc, op, sred, part + ((long)b * nblk + blk) * NPART);
+}
+
+// ---------------------------------------------------------------------------------
+// End of a time step (F2:562-577): clip to +-(1-delta), weighted mass and interior weight
+// (pass 1), then subtract mass_error/W_int on the interior nodes (pass 2) and store the
+// level into the history.  wts = hx*hy*outer(trapz_x, trapz_y) (F2:528-531), one shared plane.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTH) void k_mass(Geom G, const TrajState *__restrict__ st, long slot_stride,
+                                              const double *__restrict__ phi_s, const double *__restrict__ wts,
+                                              int do_clip, double *__restrict__ part) {
+    TILE_COORDS;
+    __shared__ double sred[NPART * 4];
+    const int slot = st[b].slot;
+    const double hi = 1.0 - DELTA_SEP;
+    double acc[2] = {0.0, 0.0};
+    for (int k = 0; k < TY / 4; ++k) {
+        int r = r0 + ly0 + 4 * k, c = c0 + lx;
+        if (r < G.ns && c < G.nf) {
+            long o = (long)r * G.pitch + c;
+            double ph = phi_s[slot * slot_stride + b * G.plane + o];
+            if (do_clip) ph = fmin(fmax(ph, -hi), hi);
+            double w = wts[o];
+            acc[0] += w * ph;
+            if (fabs(ph) < hi - 5e-3) acc[1] += w;
+        }
+    }
+    const int op[2] = {0, 0};
+    block_reduce_store<2>(acc, op, sred, part + ((long)b * nblk + blk) * NPART);
+}
+
+__global__ __launch_bounds__(NTH) void k_post(Geom G, Phys P, const TrajState *__restrict__ st, long slot_stride,
+                                              double *__restrict__ phi_s, double *__restrict__ hist_level,
+                                              long hist_stride) {
+    TILE_COORDS;
+    const TrajState S = st[b];
+    const double hi = 1.0 - DELTA_SEP;
+    const bool fix = fabs(S.mass_err) > 1e-16;
+    const bool interior_ok = S.Wint > 0.0;
+    const double shift = fix ? (interior_ok ? S.mass_err / S.Wint : S.mass_err / P.LxLy) : 0.0;
+    for (int k = 0; k < TY / 4; ++k) {
+        int r = r0 + ly0 + 4 * k, c = c0 + lx;
+        if (r < G.ns && c < G.nf) {
+            long o = (long)r * G.pitch + c;
+            long os = S.slot * slot_stride + b * G.plane + o;
+            double ph = fmin(fmax(phi_s[os], -hi), hi);
+            if (fix) {
+                if (interior_ok) {
+                    if (fabs(ph) < hi - 5e-3) ph -= shift;
+                } else {
+                    ph = fmin(fmax(ph - shift, -hi), hi);
+                }
+            }
+            phi_s[os] = ph;
+            if (hist_level) hist_level[b * hist_stride + o] = ph;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Adjoint sweep (B2:212-242).  With q = -L p carried from the previous step,
+//   rhs = B(phi_{n+1}) p_{n+1} + src = p + (tau - dt/2 D+) q + dt/2 L q + src,
+//   D+ = f''(phi_{n+1}),  src = dt/2 b1 ((phi_n - phiQ_n) + (phi_{n+1} - phiQ_{n+1})),
+// and D_n = f''(phi_n) is stored for the A(phi_n) applications; per workgroup min/max D_n.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTH) void k_adj_rhs(Geom G, Phys P, const double *__restrict__ p,
+                                                 const double *__restrict__ q, const double *__restrict__ phin,
+                                                 const double *__restrict__ phin1, const double *__restrict__ qn,
+                                                 const double *__restrict__ qn1, long hist_stride, double dt,
+                                                 double b1, double *__restrict__ rhs, double *__restrict__ Dn,
+                                                 double *__restrict__ part) {
+    TILE_COORDS;
+    __shared__ double sq[(TY + 2) * (TX + 2)];
+    __shared__ double sred[NPART * 4];
+    constexpr int W = TX + 2;
+    const long pb = b * G.plane;
+    load_tile<1>(sq, q + pb, G, c0, r0);
+    __syncthreads();
+    double acc[3] = {1e300, -1e300, 0.0};
+    for (int k = 0; k < TY / 4; ++k) {
+        int ly = ly0 + 4 * k, r = r0 + ly, c = c0 + lx;
+        if (r < G.ns && c < G.nf) {
+            int pp = (ly + 1) * W + lx + 1;
+            long o = (long)r * G.pitch + c, oh = b * hist_stride + o;
+            double f0 = phin[oh], f1 = phin1[oh];
+            double t0 = qn ? qn[oh] : 0.0, t1 = qn1 ? qn1[oh] : 0.0;
+            double src = 0.5 * dt * b1 * ((f0 - t0) + (f1 - t1));
+            double dplus = fpp_log(f1, P.c1, P.c2), dn = fpp_log(f0, P.c1, P.c2);
+            double v = p[pb + o] + (P.tau - 0.5 * dt * dplus) * sq[pp] + 0.5 * dt * lap_at<W>(sq, pp, G.ax, G.ay) + src;
+            rhs[pb + o] = v;
+            Dn[pb + o] = dn;
+            acc[0] = fmin(acc[0], dn);
+            acc[1] = fmax(acc[1], dn);
+            acc[2] += v * v;
+        }
+    }
+    const int op[3] = {1, 2, 0};
+    block_reduce_store<3>(acc, op, sred, part + ((long)b * nblk + blk) * NPART);
+}
+
+// A(phi_n) x = x + (tau + dt/2 D) M x + dt/2 M M x  (= I - tau L + dt/2 L^2 - dt/2 D L, B2:198)
+//   MODE 0: out = A x; MODE 1: out = rhs - A x with sum(out^2); MODE 2: out = B x (B2:203)
+template <int MODE>
+__global__ __launch_bounds__(NTH) void k_adj_op(Geom G, Phys P, const TrajState *__restrict__ st,
+                                                const double *__restrict__ x, const double *__restrict__ Dn,
+                                                const double *__restrict__ rhs, double dt,
+                                                double *__restrict__ out, double *__restrict__ part) {
+    TILE_COORDS;
+    if (MODE == 1 && !st[b].lin_active) return;
+    __shared__ double sx[(TY + 4) * (TX + 4)];
+    __shared__ double stt[(TY + 2) * (TX + 2)];
+    __shared__ double sred[NPART * 4];
+    constexpr int W2 = TX + 4, W1 = TX + 2;
+    const long pb = b * G.plane;
+    load_tile<2>(sx, x + pb, G, c0, r0);
+    __syncthreads();
+    for (int e = threadIdx.x; e < (TY + 2) * W1; e += NTH) {
+        int ly = e / W1, lxx = e - ly * W1;
+        stt[e] = -lap_at<W2>(sx, (ly + 1) * W2 + lxx + 1, G.ax, G.ay);      // t = M x
+    }
+    __syncthreads();
+    double acc[1] = {0.0};
+    const double sgn = MODE == 2 ? -1.0 : 1.0;
+    for (int k = 0; k < TY / 4; ++k) {
+        int ly = ly0 + 4 * k, r = r0 + ly, c = c0 + lx;
+        if (r < G.ns && c < G.nf) {
+            int p1 = (ly + 1) * W1 + lx + 1, p2 = (ly + 2) * W2 + lx + 2;
+            long o = pb + (long)r * G.pitch + c;
+            double t = stt[p1], mt = -lap_at<W1>(stt, p1, G.ax, G.ay);
+            double ax_ = sx[p2] + (P.tau + sgn * 0.5 * dt * Dn[o]) * t + sgn * 0.5 * dt * mt;
+            if (MODE == 1) {
+                double rr = rhs[o] - ax_;
+                out[o] = rr;
+                acc[0] += rr * rr;
+            } else {
+                out[o] = ax_;
+            }
+        }
+    }
+    if (MODE == 1) {
+        const int op[1] = {0};
+        block_reduce_store<1>(acc, op, sred, part + ((long)b * nblk + blk) * NPART);
+    }
+}
+
+// p_n = x (already in place); q_n = -L p_n; r_n = gb r_{n+1} + gs (q_n + q_{n+1}) (B2:233-242).
+__global__ __launch_bounds__(NTH) void k_adj_finish(Geom G, const double *__restrict__ p,
+                                                    const double *__restrict__ q_old, double *__restrict__ q_new,
+                                                    double *__restrict__ r_cur, double gb, double gs,
+                                                    double *__restrict__ r_hist, double *__restrict__ p_hist,
+                                                    double *__restrict__ q_hist, long hist_stride) {
+    TILE_COORDS;
+    __shared__ double s[(TY + 2) * (TX + 2)];
+    constexpr int W = TX + 2;
+    const long pb = b * G.plane;
+    load_tile<1>(s, p + pb, G, c0, r0);
+    __syncthreads();
+    for (int k = 0; k < TY / 4; ++k) {
+        int ly = ly0 + 4 * k, r = r0 + ly, c = c0 + lx;
+        if (r < G.ns && c < G.nf) {
+            int pp = (ly + 1) * W + lx + 1;
+            long o = (long)r * G.pitch + c, oh = b * hist_stride + o;
+            double qn = -lap_at<W>(s, pp, G.ax, G.ay);
+            double rn = q_old ? gb * r_cur[pb + o] + gs * (qn + q_old[pb + o]) : 0.0;
+            q_new[pb + o] = qn;
+            r_cur[pb + o] = rn;
+            if (r_hist) r_hist[oh] = rn;
+            if (p_hist) p_hist[oh] = s[pp];
+            if (q_hist) q_hist[oh] = qn;
+        }
+    }
+}
+
+// out = a*(x - y) (terminal right-hand side b2 (phi_M - phi_T), B2:183); y may be NULL
+__global__ __launch_bounds__(NTH) void k_scaled_diff(Geom G, const double *__restrict__ x, long xs,
+                                                     const double *__restrict__ y, long ys, double a,
+                                                     double *__restrict__ out, double *__restrict__ part) {
+    TILE_COORDS;
+    __shared__ double sred[NPART * 4];
+    double acc[1] = {0.0};
+    for (int k = 0; k < TY / 4; ++k) {
+        int r = r0 + ly0 + 4 * k, c = c0 + lx;
+        if (r < G.ns && c < G.nf) {
+            long o = (long)r * G.pitch + c;
+            double v = a * (x[b * xs + o] - (y ? y[b * ys + o] : 0.0));
+            out[b * G.plane + o] = v;
+            acc[0] += v * v;
+        }
+    }
+    const int op[1] = {0};
+    block_reduce_store<1>(acc, op, sred, part + ((long)b * nblk + blk) * NPART);
+}
+
+__global__ __launch_bounds__(NTH) void k_copy_plane(Geom G, const double *__restrict__ src, long ss,
+                                                    double *__restrict__ dst, long ds) {
+    TILE_COORDS;
+    for (int k = 0; k < TY / 4; ++k) {
+        int r = r0 + ly0 + 4 * k, c = c0 + lx;
+        if (r < G.ns && c < G.nf) {
+            long o = (long)r * G.pitch + c;
+            dst[b * ds + o] = src[b * ss + o];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Cost integrands (C2:80-106): per (trajectory, level, tile) partial sums of
+//   W (phi - phiQ)^2, W u^2, W |u| and, on the last level, W (phi - phiT)^2,
+// W = product trapezoid weights built from the caller's x, y (np.trapz arithmetic).
+// grid = (tiles, levels, B)
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTH) void k_cost(Geom G, int tiles_f, const double *__restrict__ phi,
+                                              const double *__restrict__ u, const double *__restrict__ pq,
+                                              const double *__restrict__ pt, const double *__restrict__ phi0,
+                                              const double *__restrict__ tfrac, long hist_stride, int last_level,
+                                              const double *__restrict__ W, double *__restrict__ part) {
+    const int b = blockIdx.z, lvl = blockIdx.y;
+    const int tf = blockIdx.x % tiles_f, ts = blockIdx.x / tiles_f;
+    const int c0 = tf * TX, r0 = ts * TY;
+    const int lx = threadIdx.x & 63, ly0 = threadIdx.x >> 6;
+    __shared__ double sred[NPART * 4];
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    const long lb = b * hist_stride + (long)lvl * G.plane;
+    const double tf_ = tfrac ? tfrac[lvl] : 0.0;
+    for (int k = 0; k < TY / 4; ++k) {
+        int r = r0 + ly0 + 4 * k, c = c0 + lx;
+        if (r < G.ns && c < G.nf) {
+            long o = (long)r * G.pitch + c;
+            double w = W[o], ph = phi[lb + o];
+            double uu = u ? u[lb + o] : 0.0;
+            double tq;
+            if (pq) tq = pq[lb + o];
+            else if (tfrac) tq = (1.0 - tf_) * phi0[b * G.plane + o] + tf_ * pt[b * G.plane + o];
+            else tq = 0.0;
+            double e = ph - tq;
+            acc[0] += w * (e * e);
+            acc[2] += w * (uu * uu);
+            acc[3] += w * fabs(uu);
+            if (lvl == last_level) {
+                double e2 = ph - (pt ? pt[b * G.plane + o] : 0.0);
+                acc[1] += w * (e2 * e2);
+            }
+        }
+    }
+    const int op[4] = {0, 0, 0, 0};
+    block_reduce_store<4>(acc, op, sred, part + (((long)b * gridDim.y + lvl) * gridDim.x + blockIdx.x) * 4);
+}
+
+// sums the tile partials of k_cost: out[b][lvl][4]
+__global__ void k_cost_fin(int ntiles, const double *__restrict__ part, double *__restrict__ out) {
+    const long idx = (long)blockIdx.x;      // b * levels + lvl
+    double a[4] = {0, 0, 0, 0};
+    for (int t = threadIdx.x; t < ntiles; t += 64)
+        for (int k = 0; k < 4; ++k) a[k] += part[(idx * ntiles + t) * 4 + k];
+    for (int k = 0; k < 4; ++k) {
+        double v = wave_sum(a[k]);
+        if (threadIdx.x == 0) out[idx * 4 + k] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// gradient + proximal step (C2:150, C2:191-198): g = r + b3 u; v = u - alpha g;
+// s = sign(v) max(|v| - alpha kappa_s, 0); u+ = clip(s, u_min, u_max).  Also per-workgroup
+// sum (u+ - u)^2 and sum u^2 for the relative-change stop rule (G2:375).
+// grid = (tiles, levels, B)
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTH) void k_grad_prox(Geom G, int tiles_f, const double *__restrict__ u,
+                                                   const double *__restrict__ r, long hist_stride,
+                                                   const double *__restrict__ alpha, double b3, double ks,
+                                                   double umin, double umax, double *__restrict__ uout,
+                                                   double *__restrict__ part) {
+    const int b = blockIdx.z, lvl = blockIdx.y;
+    const int tf = blockIdx.x % tiles_f, ts = blockIdx.x / tiles_f;
+    const int c0 = tf * TX, r0 = ts * TY;
+    const int lx = threadIdx.x & 63, ly0 = threadIdx.x >> 6;
+    __shared__ double sred[NPART * 4];
+    const double al = alpha[b];
+    const long lb = b * hist_stride + (long)lvl * G.plane;
+    double acc[2] = {0.0, 0.0};
+    for (int k = 0; k < TY / 4; ++k) {
+        int rr = r0 + ly0 + 4 * k, c = c0 + lx;
+        if (rr < G.ns && c < G.nf) {
+            long o = lb + (long)rr * G.pitch + c;
+            double uu = u[o];
+            double v = uu - al * (r[o] + b3 * uu);
+            double sgn = v > 0.0 ? 1.0 : (v < 0.0 ? -1.0 : 0.0);
+            double s = sgn * fmax(fabs(v) - al * ks, 0.0);
+            double un = fmin(fmax(s, umin), umax);
+            uout[o] = un;
+            acc[0] += (un - uu) * (un - uu);
+            acc[1] += uu * uu;
+        }
+    }
+    if (part) {
+        const int op[2] = {0, 0};
+        block_reduce_store<2>(acc, op, sred, part + (((long)b * gridDim.y + lvl) * gridDim.x + blockIdx.x) * 4);
+    }
+}
+
+// =================================================================================
+// `fin` kernels: one workgroup (64 threads) per trajectory; sum the per-workgroup partials
+// in a fixed order and advance the trajectory's state machine.
+// =================================================================================
+__device__ __forceinline__ void fin_reduce(const double *part, int nblk, int b, double (&out)[NPART],
+                                           const int (&op)[NPART], int n) {
+    for (int k = 0; k < n; ++k) {
+        double a = op[k] == 0 ? 0.0 : (op[k] == 1 ? 1e300 : -1e300);
+        for (int t = threadIdx.x; t < nblk; t += 64) {
+            double v = part[((long)b * nblk + t) * NPART + k];
+            a = op[k] == 0 ? a + v : (op[k] == 1 ? fmin(a, v) : fmax(a, v));
+        }
+        out[k] = op[k] == 0 ? wave_sum(a) : (op[k] == 1 ? wave_min(a) : wave_max(a));
+    }
+}
+
+constexpr int HIST_CAP = 512;          // >= max_iter + 1 residual norms (F2:353)
+constexpr double NEWTON_TOL = 1e-6;    // F2:353
+constexpr int NEWTON_MAXIT = 500;      // F2:353
+constexpr double ARMIJO_ETA = 1e-4;    // F2:394
+constexpr int ARMIJO_TRIALS = 12;      // F2:398
+
+// Start of a Newton call: arm the initial residual evaluation.
+__global__ void k_fin_newton_begin(TrajState *st) {
+    TrajState &S = st[blockIdx.x];
+    if (threadIdx.x != 0) return;
+    S.newton_active = 1;
+    S.need_trial = 1;
+    S.trial_no = 0;
+    S.force_accept = 1;     // the initial residual is always "accepted"
+    S.iters = 0;
+    S.stuck = 0;
+    S.alpha = 0.0;
+    S.lin_active = 0;
+}
+
+// After k_residual: the Armijo test (F2:411-419) or the bookkeeping of the initial residual,
+// then the Newton stop test for the new iterate (F2:364, F2:356) and the setup of the next
+// linear solve (preconditioner shift dbar = midpoint of the range of D).
+template <int MODE>
+__global__ void k_fin_residual(TrajState *st, const double *__restrict__ part, int nblk,
+                               double *__restrict__ hist, double kappa, double dt) {
+    const int b = blockIdx.x;
+    TrajState &S = st[b];
+    if (!S.newton_active || !S.need_trial) return;
+    double v[NPART];
+    const int op[NPART] = {0, 0, 1, 2, 0, 0};
+    fin_reduce(part, nblk, b, v, op, 4);
+    if (threadIdx.x != 0) return;
+    const double nt = sqrt(v[0]);
+    bool accept;
+    if (MODE == 0) {
+        accept = true;
+    } else {
+        S.ntrials++;
+        if (S.force_accept) {
+            accept = true;
+        } else {
+            if (nt < S.best_norm) { S.best_norm = nt; S.best_alpha = S.alpha; }
+            accept = nt <= (1.0 - ARMIJO_ETA * S.alpha) * S.normR;
+        }
+    }
+    if (accept) {
+        if (MODE == 1) S.slot = 1 - S.slot;
+        S.normR = nt;
+        S.need_trial = 0;
+        S.force_accept = 0;
+        if (S.iters < HIST_CAP) hist[(long)b * HIST_CAP + S.iters] = nt;
+        S.iters++;
+        S.newton_total++;
+        // F2:364: converged; F2:356: the loop body runs at most max_iter times
+        if (!(nt >= NEWTON_TOL) || S.iters > NEWTON_MAXIT) {
+            // note: a NaN norm also ends the loop here (the reference would spin on NaN)
+            if (S.iters > NEWTON_MAXIT) S.iters = NEWTON_MAXIT;
+            S.newton_active = 0;
+            return;
+        }
+        // next linear solve
+        S.Dmin = v[2];
+        S.Dmax = v[3];
+        S.dbar = 0.5 * (v[2] + v[3]);
+        {   // spectral radius of I - P^-1 A is <= (Dmax-Dmin)/2 / (dbar + 2 sqrt(kappa/(2dt)))
+            double den = S.dbar + 2.0 * sqrt(0.5 * kappa / dt);
+            S.rho = den > 0.0 ? 0.5 * (v[3] - v[2]) / den : 1.0;
+            S.theta = fmin(0.97, fmax(0.5, sqrt(S.rho)));
+        }
+        S.lin_active = 1;
+        S.lin_it = 0;
+        S.lin_r0 = sqrt(v[1]);
+        S.lin_prev = 1e300;
+        S.lin_rel = 1.0;
+        S.nsolves++;
+        if (S.lin_r0 == 0.0) S.lin_active = 0;
+    } else {
+        S.alpha *= 0.5;
+        S.trial_no++;
+        if (S.trial_no >= ARMIJO_TRIALS) {
+            if (S.best_norm < S.normR) {     // F2:422-423: fall back to the best trial
+                S.alpha = S.best_alpha;
+                S.force_accept = 1;
+            } else {
+                // F2:424-425: state unchanged -> every later iteration repeats this one
+                // bit for bit until max_iter; record that and stop.
+                S.stuck = 1;
+                S.need_trial = 0;
+                while (S.iters < NEWTON_MAXIT) {
+                    if (S.iters < HIST_CAP) hist[(long)b * HIST_CAP + S.iters] = S.normR;
+                    S.iters++;
+                }
+                S.newton_active = 0;
+            }
+        }
+    }
+}
+
+// After a Richardson residual: convergence / stagnation test of the linear solve.
+__global__ void k_fin_lin(TrajState *st, const double *__restrict__ part, int nblk, double tol, int maxit) {
+    const int b = blockIdx.x;
+    TrajState &S = st[b];
+    if (!S.lin_active) return;
+    double v[NPART];
+    const int op[NPART] = {0, 0, 0, 0, 0, 0};
+    fin_reduce(part, nblk, b, v, op, 1);
+    if (threadIdx.x != 0) return;
+    const double nr = sqrt(v[0]);
+    S.lin_it++;
+    S.lin_total++;
+    S.lin_rel = nr / S.lin_r0;
+    if (!(nr > tol * S.lin_r0) || !(nr <= S.theta * S.lin_prev) || S.lin_it >= maxit) {
+        S.lin_active = 0;
+        if (S.lin_rel > S.lin_maxrel) S.lin_maxrel = S.lin_rel;
+    }
+    S.lin_prev = nr;
+}
+
+// After k_dmu_ceiling: the step ceiling (F2:383-391) and the start of the Armijo loop.
+__global__ void k_fin_ceiling(TrajState *st, const double *__restrict__ part, int nblk) {
+    const int b = blockIdx.x;
+    TrajState &S = st[b];
+    if (!S.newton_active || S.need_trial) return;
+    double v[NPART];
+    const int op[NPART] = {1, 0, 0, 0, 0, 0};
+    fin_reduce(part, nblk, b, v, op, 1);
+    if (threadIdx.x != 0) return;
+    double amax = 2.0;
+    if (v[0] < 1e299) amax = fmin(amax, 0.9 * v[0]);
+    if (!isfinite(amax) || amax <= 0.0) amax = 1.0;
+    S.alpha = fmin(1.0, amax);
+    if (S.lin_active) {          // the host's sweep budget ran out: go on with an inexact step
+        S.lin_active = 0;
+        if (S.lin_rel > S.lin_maxrel) S.lin_maxrel = S.lin_rel;
+    }
+    S.need_trial = 1;
+    S.trial_no = 0;
+    S.force_accept = 0;
+    S.best_norm = 1e300;
+    S.best_alpha = S.alpha;
+}
+
+__global__ void k_fin_mass(TrajState *st, const double *__restrict__ part, int nblk, int init) {
+    const int b = blockIdx.x;
+    TrajState &S = st[b];
+    double v[NPART];
+    const int op[NPART] = {0, 0, 0, 0, 0, 0};
+    fin_reduce(part, nblk, b, v, op, 2);
+    if (threadIdx.x != 0) return;
+    if (init) {
+        S.mass0 = v[0];
+        S.mass_err = 0.0;
+    } else {
+        S.mass_err = v[0] - S.mass0;
+    }
+    S.Wint = v[1];
+}
+
+// Linear-solve setup outside the Newton loop.
+//   mode 0: partial slots {min D, max D, sum rhs^2}, adjoint operator A(phi_n)  (B2:198)
+//   mode 1: partial slot  {sum rhs^2}, constant-coefficient operator (D = 0)     (B2:184)
+//   mode 2: partial slots {sum(.), sum rhs^2, min D, max D}, forward Schur operator
+__global__ void k_fin_lin_begin(TrajState *st, const double *__restrict__ part, int nblk, int mode,
+                                double tau, double kappa, double dt) {
+    const int b = blockIdx.x;
+    TrajState &S = st[b];
+    double v[NPART];
+    const int op0[NPART] = {1, 2, 0, 0, 0, 0};
+    const int op1[NPART] = {0, 0, 0, 0, 0, 0};
+    const int op2[NPART] = {0, 0, 1, 2, 0, 0};
+    if (mode == 0) fin_reduce(part, nblk, b, v, op0, 3);
+    else if (mode == 1) fin_reduce(part, nblk, b, v, op1, 1);
+    else fin_reduce(part, nblk, b, v, op2, 4);
+    if (threadIdx.x != 0) return;
+    double dmin = 0.0, dmax = 0.0, r0;
+    if (mode == 0) { dmin = v[0]; dmax = v[1]; r0 = sqrt(v[2]); }
+    else if (mode == 1) { r0 = sqrt(v[0]); }
+    else { dmin = v[2]; dmax = v[3]; r0 = sqrt(v[1]); }
+    S.Dmin = dmin;
+    S.Dmax = dmax;
+    S.dbar = 0.5 * (dmin + dmax);
+    double den = mode == 2 ? S.dbar + 2.0 * sqrt(0.5 * kappa / dt)
+                           : tau + 0.5 * dt * S.dbar + 2.0 * sqrt(0.5 * dt);
+    double num = mode == 2 ? 0.5 * (dmax - dmin) : 0.25 * dt * (dmax - dmin);
+    S.rho = den > 0.0 ? num / den : 1.0;
+    S.theta = fmin(0.97, fmax(0.5, sqrt(S.rho)));
+    S.lin_r0 = r0;
+    S.lin_active = r0 > 0.0 ? 1 : 0;
+    S.lin_it = 0;
+    S.lin_prev = 1e300;
+    S.lin_rel = 1.0;
+    S.nsolves++;
+}
+
+// ---------------------------------------------------------------------------------
+// Set-up kernels of the stand-alone linear-solve entry points (kernel-level parity tests).
+// ---------------------------------------------------------------------------------
+// J [dphi;dmu] = [a;b]  ->  Schur form: R_phi := -a, rhs := b - L a, D from phi (slot 0).
+__global__ __launch_bounds__(NTH) void k_solve_setup(Geom G, Phys P, const double *__restrict__ a,
+                                                     const double *__restrict__ bv, const double *__restrict__ phi,
+                                                     double dt, double *__restrict__ Rphi, double *__restrict__ rhs,
+                                                     double *__restrict__ D, double *__restrict__ part) {
+    TILE_COORDS;
+    __shared__ double s[(TY + 2) * (TX + 2)];
+    __shared__ double sred[NPART * 4];
+    constexpr int W = TX + 2;
+    const long pb = b * G.plane;
+    load_tile<1>(s, a + pb, G, c0, r0);
+    __syncthreads();
+    double acc[4] = {0.0, 0.0, 1e300, -1e300};
+    for (int k = 0; k < TY / 4; ++k) {
+        int ly = ly0 + 4 * k, r = r0 + ly, c = c0 + lx;
+        if (r < G.ns && c < G.nf) {
+            int p = (ly + 1) * W + lx + 1;
+            long o = pb + (long)r * G.pitch + c;
+            double rh = bv[o] - lap_at<W>(s, p, G.ax, G.ay);
+            double d = jac_diag(phi[o], P.tau / dt, P.c1);
+            Rphi[o] = -s[p];
+            rhs[o] = rh;
+            D[o] = d;
+            acc[1] += rh * rh;
+            acc[2] = fmin(acc[2], d);
+            acc[3] = fmax(acc[3], d);
+        }
+    }
+    const int op[4] = {0, 0, 1, 2};
+    block_reduce_store<4>(acc, op, sred, part + ((long)b * nblk + blk) * NPART);
+}
+
+// D = f''(phi) (or 0 when phi == NULL) and sum rhs^2, min/max D: slots {min D, max D, sum rhs^2}
+__global__ __launch_bounds__(NTH) void k_adj_setup(Geom G, Phys P, const double *__restrict__ phi,
+                                                   const double *__restrict__ rhs, double *__restrict__ Dn,
+                                                   double *__restrict__ part) {
+    TILE_COORDS;
+    __shared__ double sred[NPART * 4];
+    double acc[3] = {1e300, -1e300, 0.0};
+    for (int k = 0; k < TY / 4; ++k) {
+        int r = r0 + ly0 + 4 * k, c = c0 + lx;
+        if (r < G.ns && c < G.nf) {
+            long o = b * G.plane + (long)r * G.pitch + c;
+            double d = phi ? fpp_log(phi[o], P.c1, P.c2) : 0.0;
+            Dn[o] = d;
+            acc[0] = fmin(acc[0], d);
+            acc[1] = fmax(acc[1], d);
+            if (rhs) acc[2] += rhs[o] * rhs[o];
+        }
+    }
+    const int op[3] = {1, 2, 0};
+    block_reduce_store<3>(acc, op, sred, part + ((long)b * nblk + blk) * NPART);
+}
+
+__global__ __launch_bounds__(NTH) void k_solve_w(Geom G, const double *__restrict__ w, const double *__restrict__ un,
+                                                 const double *__restrict__ unp1, double gdt, double *__restrict__ out) {
+    TILE_COORDS;
+    for (int k = 0; k < TY / 4; ++k) {
+        int r = r0 + ly0 + 4 * k, c = c0 + lx;
+        if (r < G.ns && c < G.nf) {
+            long o = b * G.plane + (long)r * G.pitch + c;
+            double u0 = un ? un[o] : 0.0, u1 = unp1 ? unp1[o] : 0.0;
+            out[o] = ((gdt - 0.5) * w[o] + 0.5 * (u1 + u0)) / (gdt + 0.5);
+        }
+    }
+}
+
+// zero-fill / constant fill of valid nodes
+__global__ __launch_bounds__(NTH) void k_fill(Geom G, double *__restrict__ x, double v) {
+    TILE_COORDS;
+    for (int k = 0; k < TY / 4; ++k) {
+        int r = r0 + ly0 + 4 * k, c = c0 + lx;
+        if (r < G.ns && c < G.nf) x[b * G.plane + (long)r * G.pitch + c] = v;
+    }
+}
+
+// phi_Q[lvl] = (1 - t_lvl/T) phi_0 + (t_lvl/T) phi_T  (build_targets choice_q = 1, G2:221-222)
+// grid = (tiles, levels, B)
+__global__ __launch_bounds__(NTH) void k_ramp(Geom G, int tiles_f, const double *__restrict__ phi0,
+                                              const double *__restrict__ phiT, const double *__restrict__ tfrac,
+                                              long hist_stride, double *__restrict__ pq) {
+    const int b = blockIdx.z, lvl = blockIdx.y;
+    const int c0 = (blockIdx.x % tiles_f) * TX, r0 = (blockIdx.x / tiles_f) * TY;
+    const int lx = threadIdx.x & 63, ly0 = threadIdx.x >> 6;
+    const double tp = tfrac[lvl];
+    for (int k = 0; k < TY / 4; ++k) {
+        int r = r0 + ly0 + 4 * k, c = c0 + lx;
+        if (r < G.ns && c < G.nf) {
+            long o = (long)r * G.pitch + c;
+            pq[b * hist_stride + (long)lvl * G.plane + o] = (1 - tp) * phi0[b * G.plane + o] + tp * phiT[b * G.plane + o];
+        }
+    }
+}
