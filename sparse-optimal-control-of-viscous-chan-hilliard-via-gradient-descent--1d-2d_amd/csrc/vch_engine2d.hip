@@ -34,6 +34,9 @@ struct vch2d_ctx {
     double *phi_s, *mu_s, *Rphi_s, *rhs_s, *D_s;
     // work planes [B][plane]
     double *w, *wnew, *mu0, *cphi, *cmu, *x, *r, *dmu, *t1, *t2;
+    double *cg_p[2], *cg_v, *cg_q;        // CG search directions / operator images
+    double *gpart;                        // [B][gnblk] partials written by the GEMM epilogue
+    int gnblk;
     double *tmp[6];
     double *wts_mass, *W_cost;            // single planes
     double *part;                         // [B][nblk][NPART]
@@ -182,7 +185,7 @@ extern "C" vch2d_ctx *vch2d_create(const vch2d_params *p, int batch, int max_ste
     c->M_res = -1;
     c->u_rows_res = 0;
     c->pgd_ready = false;
-    c->lin_maxit = 600;
+    c->lin_maxit = 4000;
     c->lin_tol = 1e-15;
     auto fail = [&](const char *what) {
         vch_fail(VCH_ERR_HIP, "vch2d_create: %s failed: %s", what, hipGetErrorString(hipGetLastError()));
@@ -196,11 +199,13 @@ extern "C" vch2d_ctx *vch2d_create(const vch2d_params *p, int batch, int max_ste
     for (auto q : two)
         if (dalloc(q, 2 * bp, c->stream)) return fail("hipMalloc");
     double **one[] = {&c->w, &c->wnew, &c->mu0, &c->cphi, &c->cmu, &c->x, &c->r, &c->dmu, &c->t1, &c->t2,
-                      &c->tmp[0], &c->tmp[1], &c->tmp[2], &c->tmp[3], &c->tmp[4], &c->tmp[5], &c->phiT, &c->phi0};
+                      &c->cg_p[0], &c->cg_p[1], &c->cg_v, &c->cg_q, &c->tmp[0], &c->tmp[1], &c->tmp[2], &c->tmp[3], &c->tmp[4], &c->tmp[5], &c->phiT, &c->phi0};
     for (auto q : one)
         if (dalloc(q, bp, c->stream)) return fail("hipMalloc");
     if (dalloc(&c->wts_mass, G.plane, c->stream) || dalloc(&c->W_cost, G.plane, c->stream)) return fail("hipMalloc");
     if (dalloc(&c->part, (size_t)batch * c->nblk * NPART, c->stream)) return fail("hipMalloc");
+    c->gnblk = ((G.nf + GN - 1) / GN) * ((G.ns + GM - 1) / GM);
+    if (dalloc(&c->gpart, (size_t)batch * c->gnblk, c->stream)) return fail("hipMalloc");
     if (dalloc(&c->hist_dev, (size_t)batch * HIST_CAP, c->stream)) return fail("hipMalloc");
     if (dalloc(&c->alpha_dev, batch, c->stream) || dalloc(&c->J_dev, 5 * (size_t)batch, c->stream)) return fail("hipMalloc");
     if (hipMalloc((void **)&c->st, sizeof(TrajState) * batch) != hipSuccess) return fail("hipMalloc");
@@ -244,7 +249,7 @@ extern "C" void vch2d_destroy(vch2d_ctx *c) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     double *all[] = {c->phi_s, c->mu_s, c->Rphi_s, c->rhs_s, c->D_s, c->w, c->wnew, c->mu0, c->cphi, c->cmu, c->x,
-                     c->r, c->dmu, c->t1, c->t2, c->tmp[0], c->tmp[1], c->tmp[2], c->tmp[3], c->tmp[4], c->tmp[5],
+                     c->r, c->dmu, c->t1, c->t2, c->cg_p[0], c->cg_p[1], c->cg_v, c->cg_q, c->gpart, c->tmp[0], c->tmp[1], c->tmp[2], c->tmp[3], c->tmp[4], c->tmp[5],
                      c->phiT, c->phi0, c->wts_mass, c->W_cost, c->part, c->hist_dev, c->alpha_dev, c->J_dev, c->Q1f,
                      c->Q2f, c->Q1s, c->Q2s, c->mf, c->ms, c->phi_hist, c->u_hist, c->u_trial, c->phi_trial, c->phiQ,
                      c->r_hist, c->p_hist, c->q_hist, c->cost_part, c->cost_lvl, c->tfrac_dev};
@@ -273,14 +278,16 @@ extern "C" int vch2d_batch(const vch2d_ctx *c) { return c ? c->B : VCH_ERR_ARG; 
     } while (0)
 
 // ------------------------------------------------------------------------------------
-// fast-diagonalisation preconditioner:  out (+)= (c0 + m (c1a + c1b dbar + c2 m))^-1 in
+// fast-diagonalisation preconditioner:  out = (c0 + m (c1a + c1b dbar + c2 m))^-1 in
+//   last: 0 store; 3 store + partial of sum W (D[slot] - dbar) other*out into c->gpart
+//         (other == NULL: out*out)
 // ------------------------------------------------------------------------------------
-static int precond(vch2d_ctx *c, const double *in, long in_slot_stride, double *out, bool accumulate,
+static int precond(vch2d_ctx *c, const double *in, long in_slot_stride, double *out, int last, const double *other,
                    double c0, double c1a, double c1b, double c2, int gate) {
     const Geom &G = c->G;
     const int ns = G.ns, nf = G.nf;
     dim3 g((nf + GN - 1) / GN, (ns + GM - 1) / GM, c->B);
-    SpecArgs sp{c0, c1a, c1b, c2, c->ms, c->mf};
+    SpecArgs sp{c0, c1a, c1b, c2, c->ms, c->mf, other, c->D_s, c->slot_stride, c->gpart};
     // T1 = g Q1f
     LAUNCH((k_gemm<false, 0>), g, dim3(256), ns, nf, nf, in, (long)G.pitch, G.plane, in_slot_stride, c->Q1f, (long)nf, 0L,
            c->t1, (long)G.pitch, G.plane, sp, c->st, gate);
@@ -290,9 +297,9 @@ static int precond(vch2d_ctx *c, const double *in, long in_slot_stride, double *
     // T3 = Q2s^T T2
     LAUNCH((k_gemm<true, 0>), g, dim3(256), ns, nf, ns, c->Q2s, (long)ns, 0L, 0L, c->t2, (long)G.pitch, G.plane, c->t1,
            (long)G.pitch, G.plane, sp, c->st, gate);
-    // out (+)= T3 Q2f
-    if (accumulate)
-        LAUNCH((k_gemm<false, 2>), g, dim3(256), ns, nf, nf, c->t1, (long)G.pitch, G.plane, 0L, c->Q2f, (long)nf, 0L, out,
+    // out = T3 Q2f
+    if (last == 3)
+        LAUNCH((k_gemm<false, 3>), g, dim3(256), ns, nf, nf, c->t1, (long)G.pitch, G.plane, 0L, c->Q2f, (long)nf, 0L, out,
                (long)G.pitch, G.plane, sp, c->st, gate);
     else
         LAUNCH((k_gemm<false, 0>), g, dim3(256), ns, nf, nf, c->t1, (long)G.pitch, G.plane, 0L, c->Q2f, (long)nf, 0L, out,
@@ -300,34 +307,56 @@ static int precond(vch2d_ctx *c, const double *in, long in_slot_stride, double *
     return 0;
 }
 
-// number of Richardson sweeps to enqueue for the worst contraction bound of the batch
-static int sweeps_for(const vch2d_ctx *c, bool only_newton_active) {
-    double rho = 0.0;
-    bool any = false;
+// CG iterations to enqueue: the largest rigorous bound among the trajectories still solving
+static int cg_budget(const vch2d_ctx *c, bool only_newton_active) {
+    int n = 0;
     for (int b = 0; b < c->B; ++b) {
         const TrajState &S = c->st_host[b];
         if (!S.lin_active) continue;
         if (only_newton_active && !S.newton_active) continue;
-        any = true;
-        rho = std::max(rho, S.rho);
+        n = std::max(n, S.lin_budget);
     }
-    if (!any) return 0;
-    if (!(rho < 0.999)) return c->lin_maxit;
-    if (rho < 1e-12) return 3;
-    int n = (int)std::ceil(std::log(1e-16) / std::log(rho)) + 3;
-    return std::max(3, std::min(n, c->lin_maxit));
+    return std::min(n, c->lin_maxit);
 }
+static bool any_lin_active(const vch2d_ctx *c) {
+    for (int b = 0; b < c->B; ++b)
+        if (c->st_host[b].lin_active) return true;
+    return false;
+}
+constexpr int CG_CHUNK = 24;      // iterations enqueued between two looks at the state
 
-// Richardson sweeps on the Schur system of the current Newton iterate; x := dphi.
-static int schur_solve(vch2d_ctx *c, double dt, int nsweeps) {
-    for (int it = 0; it < nsweeps; ++it) {
-        if (it == 0)      // x = P^-1 rhs
-            VCHCHK(precond(c, c->rhs_s, c->slot_stride, c->x, false, 1.0 / dt, 0.0, 1.0, 0.5 * c->P.kappa, 1));
-        else
-            VCHCHK(precond(c, c->r, 0, c->x, true, 1.0 / dt, 0.0, 1.0, 0.5 * c->P.kappa, 1));
-        LAUNCH((k_schur<1>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->x, c->D_s, c->rhs_s, dt, c->r,
-               c->part);
-        LAUNCH(k_fin_lin, dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->lin_tol, c->lin_maxit);
+// CG on the Schur system of the current Newton iterate (left-preconditioned, weighted inner
+// product W (D - dbar)); on return x = dphi.  `budget` from cg_budget() of the last sync.
+static int schur_solve(vch2d_ctx *c, double dt, int budget) {
+    if (budget <= 0) return 0;
+    const double c0 = 1.0 / dt, c2 = 0.5 * c->P.kappa;
+    HIPCHK(hipMemsetAsync(c->x, 0, sizeof(double) * c->B * c->G.plane, c->stream));
+    double *z = c->r;
+    VCHCHK(precond(c, c->rhs_s, c->slot_stride, z, 3, nullptr, c0, 0.0, 1.0, c2, 1));      // z = P^-1 rhs, <z,z>_Z
+    LAUNCH(k_fin_cg_init, dim3(c->B), dim3(64), c->st, c->gpart, c->gnblk);
+    int done = 0;
+    while (done < budget) {
+        const int chunk = std::min(budget - done, CG_CHUNK);
+        for (int j = 0; j < chunk; ++j, ++done) {
+            double *pn = c->cg_p[done & 1], *po = c->cg_p[(done + 1) & 1];
+            if (done == 0) {
+                LAUNCH((k_schur_p<1>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, z, po, c->D_s, dt, pn, c->cg_v);
+            } else {
+                LAUNCH((k_schur_p<0>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, z, po, c->D_s, dt, pn, c->cg_v);
+            }
+            VCHCHK(precond(c, c->cg_v, 0, c->cg_q, 3, pn, c0, 0.0, 1.0, c2, 1));           // q = P^-1 A p, <p,q>_Z
+            LAUNCH(k_fin_cg_alpha, dim3(c->B), dim3(64), c->st, c->gpart, c->gnblk, 1, 0);
+            if (done == 0) {
+                LAUNCH((k_cg_update<1>), c->grid, dim3(NTH), c->G, c->st, c->slot_stride, pn, c->cg_q, c->D_s, c->x, z, c->part);
+            } else {
+                LAUNCH((k_cg_update<0>), c->grid, dim3(NTH), c->G, c->st, c->slot_stride, pn, c->cg_q, c->D_s, c->x, z, c->part);
+            }
+            LAUNCH(k_fin_cg_beta, dim3(c->B), dim3(64), c->st, c->part, c->nblk, 0, c->lin_tol, c->lin_maxit, 0);
+        }
+        if (done < budget) {
+            VCHCHK(sync_state(c));
+            if (!any_lin_active(c)) break;
+        }
     }
     return 0;
 }
@@ -341,7 +370,7 @@ static int newton_level(vch2d_ctx *c, double dt, const double *un, const double 
     LAUNCH(k_fin_newton_begin, dim3(c->B), dim3(64), c->st);
     LAUNCH((k_residual<0>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s, c->Rphi_s, c->rhs_s,
            c->D_s, c->mu0, c->x, c->dmu, c->cphi, c->cmu, dt, c->part);
-    LAUNCH((k_fin_residual<0>), dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->hist_dev, c->P.kappa, dt);
+    LAUNCH((k_fin_residual<0>), dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->hist_dev, c->P.kappa, dt, c->lin_tol);
     VCHCHK(sync_state(c));
     auto any_active = [&]() {
         for (int b = 0; b < c->B; ++b)
@@ -356,7 +385,7 @@ static int newton_level(vch2d_ctx *c, double dt, const double *un, const double 
     int guard = 0;
     while (any_active()) {
         if (++guard > NEWTON_MAXIT + 2) return vch_fail(VCH_ERR_STATE, "newton_level: state machine did not terminate");
-        VCHCHK(schur_solve(c, dt, sweeps_for(c, true)));
+        VCHCHK(schur_solve(c, dt, cg_budget(c, true)));
         LAUNCH(k_dmu_ceiling, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->x, c->phi_s, c->D_s, c->Rphi_s,
                c->dmu, c->part);
         LAUNCH(k_fin_ceiling, dim3(c->B), dim3(64), c->st, c->part, c->nblk);
@@ -364,7 +393,7 @@ static int newton_level(vch2d_ctx *c, double dt, const double *un, const double 
         do {
             LAUNCH((k_residual<1>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s, c->Rphi_s,
                    c->rhs_s, c->D_s, c->mu0, c->x, c->dmu, c->cphi, c->cmu, dt, c->part);
-            LAUNCH((k_fin_residual<1>), dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->hist_dev, c->P.kappa, dt);
+            LAUNCH((k_fin_residual<1>), dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->hist_dev, c->P.kappa, dt, c->lin_tol);
             VCHCHK(sync_state(c));
             if (++tguard > ARMIJO_TRIALS + 2) return vch_fail(VCH_ERR_STATE, "newton_level: Armijo loop did not terminate");
         } while (any_trial());
@@ -480,7 +509,7 @@ extern "C" int vch2d_spectral_solve(vch2d_ctx *c, double c0, double c1, double c
     CTXCHK(c);
     ARGCHK(v && out, "NULL array");
     VCHCHK(h2d(c, c->tmp[0], v, c->B));
-    VCHCHK(precond(c, c->tmp[0], 0, c->tmp[1], false, c0, c1, 0.0, c2, 0));
+    VCHCHK(precond(c, c->tmp[0], 0, c->tmp[1], 0, nullptr, c0, c1, 0.0, c2, 0));
     return d2h(c, out, c->tmp[1], c->B);
 }
 
@@ -497,9 +526,9 @@ extern "C" int vch2d_jacobian_solve(vch2d_ctx *c, const double *phi_new, double 
     HIPCHK(hipMemcpyAsync(c->phi_s, c->tmp[0], sizeof(double) * c->B * c->G.plane, hipMemcpyDeviceToDevice, c->stream));
     LAUNCH(k_solve_setup, c->grid, dim3(NTH), c->G, c->P, c->tmp[1], c->tmp[2], c->tmp[0], dt, c->Rphi_s, c->rhs_s, c->D_s,
            c->part);
-    LAUNCH(k_fin_lin_begin, dim3(c->B), dim3(64), c->st, c->part, c->nblk, 2, c->P.tau, c->P.kappa, dt);
+    LAUNCH(k_fin_lin_begin, dim3(c->B), dim3(64), c->st, c->part, c->nblk, 2, c->P.tau, c->P.kappa, dt, c->lin_tol);
     VCHCHK(sync_state(c));
-    VCHCHK(schur_solve(c, dt, sweeps_for(c, false)));
+    VCHCHK(schur_solve(c, dt, cg_budget(c, false)));
     // back substitution needs newton_active && !need_trial
     HIPCHK(hipStreamSynchronize(c->stream));
     {   // keep the device-side linear-solve results, flip only the two flags
@@ -524,15 +553,29 @@ extern "C" int vch2d_jacobian_solve(vch2d_ctx *c, const double *phi_new, double 
 // ------------------------------------------------------------------------------------
 // adjoint operator / solve
 // ------------------------------------------------------------------------------------
-// Richardson sweeps for A(phi_n) x = rhs (buffers: x = c->x, rhs = c->cphi, D_n = c->cmu, r = c->r)
-static int adjoint_solve_sweeps(vch2d_ctx *c, double dt, int nsweeps) {
-    // initial residual of the initial guess
+// CG for A(phi_n) x = rhs, right-preconditioned, weighted inner product W / (D_n - dbar);
+// initial guess = current content of c->x.  Buffers: rhs = c->cphi, D_n = c->cmu, r = c->r.
+static int adjoint_solve_cg(vch2d_ctx *c, double dt, int budget) {
+    double *ph = c->cg_p[0], *pv = c->cg_p[1], *q = c->cg_q;
+    // r = rhs - A x0, <r,r>_Z', ||r||_2
     LAUNCH((k_adj_op<1>), c->grid, dim3(NTH), c->G, c->P, c->st, c->x, c->cmu, c->cphi, dt, c->r, c->part);
-    LAUNCH(k_fin_lin, dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->lin_tol, c->lin_maxit);
-    for (int it = 0; it < nsweeps; ++it) {
-        VCHCHK(precond(c, c->r, 0, c->x, true, 1.0, c->P.tau, 0.5 * dt, 0.5 * dt, 1));
-        LAUNCH((k_adj_op<1>), c->grid, dim3(NTH), c->G, c->P, c->st, c->x, c->cmu, c->cphi, dt, c->r, c->part);
-        LAUNCH(k_fin_lin, dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->lin_tol, c->lin_maxit);
+    LAUNCH(k_fin_cg_beta, dim3(c->B), dim3(64), c->st, c->part, c->nblk, 1, c->lin_tol, c->lin_maxit, 1);
+    int done = 0;
+    while (done < budget) {
+        const int chunk = std::min(budget - done, CG_CHUNK);
+        for (int j = 0; j < chunk; ++j, ++done) {
+            if (done == 0) LAUNCH((k_cg_dir<1>), c->grid, dim3(NTH), c->G, c->st, c->r, ph);
+            else LAUNCH((k_cg_dir<0>), c->grid, dim3(NTH), c->G, c->st, c->r, ph);
+            VCHCHK(precond(c, ph, 0, pv, 0, nullptr, 1.0, c->P.tau, 0.5 * dt, 0.5 * dt, 1));
+            LAUNCH(k_adj_q, c->grid, dim3(NTH), c->G, c->P, c->st, pv, c->cmu, ph, dt, q, c->part);
+            LAUNCH(k_fin_cg_alpha, dim3(c->B), dim3(64), c->st, c->part, c->nblk, NPART, 0);
+            LAUNCH(k_cg_update_adj, c->grid, dim3(NTH), c->G, c->st, pv, q, c->cmu, c->x, c->r, c->part);
+            LAUNCH(k_fin_cg_beta, dim3(c->B), dim3(64), c->st, c->part, c->nblk, 1, c->lin_tol, c->lin_maxit, 0);
+        }
+        if (done < budget) {
+            VCHCHK(sync_state(c));
+            if (!any_lin_active(c)) break;
+        }
     }
     return 0;
 }
@@ -560,10 +603,10 @@ extern "C" int vch2d_adjoint_solve(vch2d_ctx *c, const double *phi_n, double dt,
     VCHCHK(h2d(c, c->cphi, rhs, c->B));
     LAUNCH(k_adj_setup, c->grid, dim3(NTH), c->G, c->P, (dt > 0 ? c->tmp[0] : (const double *)nullptr), c->cphi, c->cmu,
            c->part);
-    LAUNCH(k_fin_lin_begin, dim3(c->B), dim3(64), c->st, c->part, c->nblk, 0, c->P.tau, c->P.kappa, dt);
+    LAUNCH(k_fin_lin_begin, dim3(c->B), dim3(64), c->st, c->part, c->nblk, 0, c->P.tau, c->P.kappa, dt, c->lin_tol);
     LAUNCH(k_fill, c->grid, dim3(NTH), c->G, c->x, 0.0);
     VCHCHK(sync_state(c));
-    VCHCHK(adjoint_solve_sweeps(c, dt, sweeps_for(c, false)));
+    VCHCHK(adjoint_solve_cg(c, dt, cg_budget(c, false)));
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     VCHCHK(d2h(c, p_out, c->x, c->B));
     VCHCHK(sync_state(c));
@@ -686,9 +729,9 @@ static int backward_core(vch2d_ctx *c, const double *phi_hist_dev, int M, const 
     // terminal condition (B2:183-187): (I - tau L) p_M = b2 (phi_M - phi_T), q_M = -L p_M, r_M = 0
     LAUNCH(k_scaled_diff, c->grid, dim3(NTH), G, phi_hist_dev + (long)M * G.plane, hs, phiT_dev, G.plane, b2, rhs, c->part);
     LAUNCH(k_adj_setup, c->grid, dim3(NTH), G, c->P, (const double *)nullptr, (const double *)rhs, Dn, c->part);
-    LAUNCH(k_fin_lin_begin, dim3(c->B), dim3(64), c->st, c->part, c->nblk, 0, c->P.tau, c->P.kappa, 0.0);
+    LAUNCH(k_fin_lin_begin, dim3(c->B), dim3(64), c->st, c->part, c->nblk, 0, c->P.tau, c->P.kappa, 0.0, c->lin_tol);
     LAUNCH(k_fill, c->grid, dim3(NTH), G, c->x, 0.0);
-    VCHCHK(adjoint_solve_sweeps(c, 0.0, 3));
+    VCHCHK(adjoint_solve_cg(c, 0.0, 3));
     LAUNCH(k_adj_finish, c->grid, dim3(NTH), G, c->x, (const double *)nullptr, qa, rcur, 0.0, 0.0,
            r_out ? r_out + (long)M * G.plane : (double *)nullptr, p_out ? p_out + (long)M * G.plane : (double *)nullptr,
            q_out ? q_out + (long)M * G.plane : (double *)nullptr, hs);
@@ -706,9 +749,9 @@ static int backward_core(vch2d_ctx *c, const double *phi_hist_dev, int M, const 
         LAUNCH(k_adj_rhs, c->grid, dim3(NTH), G, c->P, c->x, qa, phi_hist_dev + (long)n * G.plane,
                phi_hist_dev + (long)(n + 1) * G.plane, phiQ_dev ? phiQ_dev + (long)n * G.plane : (const double *)nullptr,
                phiQ_dev ? phiQ_dev + (long)(n + 1) * G.plane : (const double *)nullptr, hs, dtn, b1, rhs, Dn, c->part);
-        LAUNCH(k_fin_lin_begin, dim3(c->B), dim3(64), c->st, c->part, c->nblk, 0, c->P.tau, c->P.kappa, dtn);
+        LAUNCH(k_fin_lin_begin, dim3(c->B), dim3(64), c->st, c->part, c->nblk, 0, c->P.tau, c->P.kappa, dtn, c->lin_tol);
         VCHCHK(sync_state(c));
-        VCHCHK(adjoint_solve_sweeps(c, dtn, sweeps_for(c, false)));
+        VCHCHK(adjoint_solve_cg(c, dtn, cg_budget(c, false)));
         const double den = c->P.gamma + 0.5 * dtn;
         LAUNCH(k_adj_finish, c->grid, dim3(NTH), G, c->x, qa, qb, rcur, (c->P.gamma - 0.5 * dtn) / den, (0.5 * dtn) / den, rl,
                pl, ql, hs);

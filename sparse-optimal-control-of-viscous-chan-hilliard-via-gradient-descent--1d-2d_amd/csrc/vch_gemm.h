@@ -30,9 +30,14 @@ constexpr int LDI = 17;     // row stride of [i][k] LDS images
 struct SpecArgs {           // multiplier = 1 / (c0 + m (c1a + c1b*dbar[b] + c2 m)), m = ms[row] + mf[col]
     double c0, c1a, c1b, c2;
     const double *ms, *mf;
+    // EPI 3: per-workgroup partial of  sum W (D - dbar) other * C  (other == NULL: C * C)
+    const double *other;     // [B][plane]
+    const double *Dslot;     // slot-indexed D planes
+    long d_slot_stride;
+    double *gpart;           // [B][gridDim.x*gridDim.y]
 };
 
-// EPI: 0 store, 1 store * spectral multiplier, 2 accumulate (C += A B)
+// EPI: 0 store, 1 store * spectral multiplier, 2 accumulate (C += A B), 3 store + weighted dot partial
 // A_KMAJOR: A is stored [K][M] (lda = row length M-side), else [M][K].
 // gate: 0 none, 1 only trajectories with lin_active
 template <bool A_KMAJOR, int EPI>
@@ -101,8 +106,14 @@ __global__ __launch_bounds__(256) void k_gemm(int M, int N, int K, const double 
         __syncthreads();
     }
     double *Cb = C + b * sC;
-    double c1 = 0.0;
+    double c1 = 0.0, dot = 0.0, dbar = 0.0;
+    const double *Dp = nullptr, *Ob = nullptr;
     if (EPI == 1) c1 = sp.c1a + sp.c1b * st[b].dbar;
+    if (EPI == 3) {
+        dbar = st[b].dbar;
+        Dp = sp.Dslot + st[b].slot * sp.d_slot_stride + b * sC;
+        Ob = sp.other ? sp.other + b * sC : nullptr;
+    }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -119,8 +130,20 @@ __global__ __launch_bounds__(256) void k_gemm(int M, int N, int K, const double 
                         v = v / (sp.c0 + m * (c1 + sp.c2 * m));
                     } else if (EPI == 2) {
                         v += Cb[o];
+                    } else if (EPI == 3) {
+                        double wgt = ((row == 0 || row == M - 1) ? 0.5 : 1.0) * ((col == 0 || col == N - 1) ? 0.5 : 1.0);
+                        dot += wgt * (Dp[o] - dbar) * ((Ob ? Ob[o] : v) * v);
                     }
                     Cb[o] = v;
                 }
             }
+    if (EPI == 3) {
+        dot = wave_sum(dot);
+        __syncthreads();
+        if (lane == 0) As[wv] = dot;
+        __syncthreads();
+        if (tid == 0)
+            sp.gpart[(long)b * (gridDim.x * gridDim.y) + blockIdx.y * gridDim.x + blockIdx.x] =
+                (As[0] + As[1]) + (As[2] + As[3]);
+    }
 }

@@ -32,10 +32,13 @@ struct TrajState {
     double Dmin, Dmax, dbar;   // range of the Jacobian diagonal, preconditioner shift
     double rho, theta;         // contraction bound of the Richardson sweep, stagnation threshold
     long newton_total;         // residual norms recorded over the whole march
-    // linear solve (preconditioned Richardson on the Schur system)
+    // linear solve (preconditioned CG on the Schur system)
     int lin_active, lin_it;
     long lin_total;
     double lin_r0, lin_prev, lin_rel, lin_maxrel;
+    // conjugate gradients in the weighted inner product (see k_schur_p)
+    double cg_gamma, cg_gamma0, cg_alpha, cg_beta;
+    int lin_budget, cg_pad;    // rigorous iteration bound from the spectrum of P^-1 A
     // mass fix (F2:565-577)
     double mass0, mass_err, Wint;
     // scratch for cost / change norms
@@ -102,6 +105,12 @@ __device__ __forceinline__ double jac_diag(double phi, double tau_dt, double c1)
 __device__ __forceinline__ double fpp_log(double phi, double c1, double c2) {   // B2:71-72
     double p = fmin(fmax(phi, -1.0 + 1e-8), 1.0 - 1e-8);
     return 2.0 * c1 / (1.0 - p * p) - 2.0 * c2;
+}
+
+// trapezoid weight of node (r, c) of the plane as the engine stores it; M = -L is self-adjoint
+// in the inner product weighted by it (W L is symmetric)
+__device__ __forceinline__ double wdev(int r, int c, const Geom &G) {
+    return ((r == 0 || r == G.ns - 1) ? 0.5 : 1.0) * ((c == 0 || c == G.nf - 1) ? 0.5 : 1.0);
 }
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -566,6 +575,7 @@ __global__ __launch_bounds__(NTH) void k_adj_op(Geom G, Phys P, const TrajState 
                                                 double *__restrict__ out, double *__restrict__ part) {
     TILE_COORDS;
     if (MODE == 1 && !st[b].lin_active) return;
+    const double dbar = MODE == 1 ? st[b].dbar : 0.0;
     __shared__ double sx[(TY + 4) * (TX + 4)];
     __shared__ double stt[(TY + 2) * (TX + 2)];
     __shared__ double sred[NPART * 4];
@@ -578,7 +588,7 @@ __global__ __launch_bounds__(NTH) void k_adj_op(Geom G, Phys P, const TrajState 
         stt[e] = -lap_at<W2>(sx, (ly + 1) * W2 + lxx + 1, G.ax, G.ay);      // t = M x
     }
     __syncthreads();
-    double acc[1] = {0.0};
+    double acc[2] = {0.0, 0.0};
     const double sgn = MODE == 2 ? -1.0 : 1.0;
     for (int k = 0; k < TY / 4; ++k) {
         int ly = ly0 + 4 * k, r = r0 + ly, c = c0 + lx;
@@ -590,15 +600,16 @@ __global__ __launch_bounds__(NTH) void k_adj_op(Geom G, Phys P, const TrajState 
             if (MODE == 1) {
                 double rr = rhs[o] - ax_;
                 out[o] = rr;
-                acc[0] += rr * rr;
+                acc[0] += wdev(r, c, G) / (Dn[o] - dbar) * (rr * rr);
+                acc[1] += rr * rr;
             } else {
                 out[o] = ax_;
             }
         }
     }
     if (MODE == 1) {
-        const int op[1] = {0};
-        block_reduce_store<1>(acc, op, sred, part + ((long)b * nblk + blk) * NPART);
+        const int op[2] = {0, 0};
+        block_reduce_store<2>(acc, op, sred, part + ((long)b * nblk + blk) * NPART);
     }
 }
 
@@ -795,9 +806,29 @@ __global__ void k_fin_newton_begin(TrajState *st) {
 // After k_residual: the Armijo test (F2:411-419) or the bookkeeping of the initial residual,
 // then the Newton stop test for the new iterate (F2:364, F2:356) and the setup of the next
 // linear solve (preconditioner shift dbar = midpoint of the range of D).
+// Preconditioner shift and CG iteration budget.  With A = P + M (D - dbar) (forward) or
+// A = P + c (D - dbar) M (adjoint, c = dt/2), P the constant-coefficient operator with shift
+// dbar < min D, the preconditioned operator is self-adjoint and positive in the inner product
+// weighted by W (D - dbar) (forward, left preconditioning) resp. W / (D - dbar) (adjoint, right
+// preconditioning), with spectrum in [1, kappa_T], kappa_T <= 1 + c (Dmax - dbar) / (c dbar + g0),
+// g0 = lower bound of (P - c dbar M)/M.  CG therefore needs at most
+// ln(2/tol) / -ln((sqrt(kappa_T)-1)/(sqrt(kappa_T)+1)) iterations.
+__device__ __forceinline__ void cg_setup(TrajState &S, double g0, double cscale, double tol) {
+    const double range = S.Dmax - S.Dmin;
+    S.dbar = S.Dmin - fmax(1e-12, 0.05 * fmin(range, fabs(S.Dmin) + 1.0));
+    const double den = cscale * S.dbar + g0;
+    double kT = den > 0.0 ? 1.0 + cscale * (S.Dmax - S.dbar) / den : 1e12;
+    const double sq = sqrt(kT);
+    const double rate = (sq - 1.0) / (sq + 1.0);
+    S.rho = rate;
+    double k = rate > 1e-300 ? log(2.0 / tol) / -log(rate) : 1.0;
+    S.lin_budget = (int)fmin(4000.0, ceil(k) + 2.0);
+    S.theta = 0.0;
+}
+
 template <int MODE>
 __global__ void k_fin_residual(TrajState *st, const double *__restrict__ part, int nblk,
-                               double *__restrict__ hist, double kappa, double dt) {
+                               double *__restrict__ hist, double kappa, double dt, double lin_tol) {
     const int b = blockIdx.x;
     TrajState &S = st[b];
     if (!S.newton_active || !S.need_trial) return;
@@ -836,12 +867,7 @@ __global__ void k_fin_residual(TrajState *st, const double *__restrict__ part, i
         // next linear solve
         S.Dmin = v[2];
         S.Dmax = v[3];
-        S.dbar = 0.5 * (v[2] + v[3]);
-        {   // spectral radius of I - P^-1 A is <= (Dmax-Dmin)/2 / (dbar + 2 sqrt(kappa/(2dt)))
-            double den = S.dbar + 2.0 * sqrt(0.5 * kappa / dt);
-            S.rho = den > 0.0 ? 0.5 * (v[3] - v[2]) / den : 1.0;
-            S.theta = fmin(0.97, fmax(0.5, sqrt(S.rho)));
-        }
+        cg_setup(S, 2.0 * sqrt(0.5 * kappa / dt), 1.0, lin_tol);
         S.lin_active = 1;
         S.lin_it = 0;
         S.lin_r0 = sqrt(v[1]);
@@ -871,24 +897,70 @@ __global__ void k_fin_residual(TrajState *st, const double *__restrict__ part, i
     }
 }
 
-// After a Richardson residual: convergence / stagnation test of the linear solve.
-__global__ void k_fin_lin(TrajState *st, const double *__restrict__ part, int nblk, double tol, int maxit) {
+// ---- CG scalar updates (one thread per trajectory does the arithmetic) ----
+// gpart: partials written by the GEMM epilogue (gnblk per trajectory, 1 value each)
+__device__ __forceinline__ double fin_sum1(const double *part, int n, int b, int stride, int k) {
+    double a = 0.0;
+    for (int t = threadIdx.x; t < n; t += 64) a += part[((long)b * n + t) * stride + k];
+    return wave_sum(a);
+}
+
+// forward set-up: gamma0 = <z, z>_Z with z = P^-1 rhs (from the GEMM epilogue)
+__global__ void k_fin_cg_init(TrajState *st, const double *__restrict__ gpart, int gnblk) {
     const int b = blockIdx.x;
     TrajState &S = st[b];
     if (!S.lin_active) return;
-    double v[NPART];
-    const int op[NPART] = {0, 0, 0, 0, 0, 0};
-    fin_reduce(part, nblk, b, v, op, 1);
+    double g = fin_sum1(gpart, gnblk, b, 1, 0);
     if (threadIdx.x != 0) return;
-    const double nr = sqrt(v[0]);
-    S.lin_it++;
-    S.lin_total++;
-    S.lin_rel = nr / S.lin_r0;
-    if (!(nr > tol * S.lin_r0) || !(nr <= S.theta * S.lin_prev) || S.lin_it >= maxit) {
+    S.cg_gamma = S.cg_gamma0 = g;
+    S.cg_beta = 0.0;
+    S.lin_it = 0;
+    S.lin_rel = 1.0;
+    if (!(g > 0.0)) S.lin_active = 0;        // zero right-hand side: x = 0 is the solution
+}
+
+// alpha = gamma / <p, q>_Z ; src 0: GEMM partials (1 value), src 1: stencil partials (slot k)
+__global__ void k_fin_cg_alpha(TrajState *st, const double *__restrict__ part, int n, int stride, int k) {
+    const int b = blockIdx.x;
+    TrajState &S = st[b];
+    if (!S.lin_active) return;
+    double pq = fin_sum1(part, n, b, stride, k);
+    if (threadIdx.x != 0) return;
+    if (!(pq > 0.0)) {                       // breakdown (round-off level residual): stop here
+        S.lin_active = 0;
+        S.cg_alpha = 0.0;
+        if (S.lin_rel > S.lin_maxrel) S.lin_maxrel = S.lin_rel;
+        return;
+    }
+    S.cg_alpha = S.cg_gamma / pq;
+}
+
+// beta = gamma_new / gamma; convergence test.  mode 0 (forward): relative decrease of the
+// Z-norm of the preconditioned residual; mode 1 (adjoint): ||r||_2 / ||rhs||_2 (slot k+1).
+__global__ void k_fin_cg_beta(TrajState *st, const double *__restrict__ part, int nblk, int mode, double tol,
+                              int maxit, int init) {
+    const int b = blockIdx.x;
+    TrajState &S = st[b];
+    if (!S.lin_active) return;
+    double gn = fin_sum1(part, nblk, b, NPART, 0);
+    double rr = mode == 1 ? fin_sum1(part, nblk, b, NPART, 1) : 0.0;
+    if (threadIdx.x != 0) return;
+    if (init) {
+        S.cg_gamma = S.cg_gamma0 = gn;
+        S.cg_beta = 0.0;
+        S.lin_it = 0;
+    } else {
+        S.cg_beta = S.cg_gamma > 0.0 ? gn / S.cg_gamma : 0.0;
+        S.cg_gamma = gn;
+        S.lin_it++;
+        S.lin_total++;
+    }
+    S.lin_rel = mode == 1 ? (S.lin_r0 > 0.0 ? sqrt(rr) / S.lin_r0 : 0.0)
+                          : (S.cg_gamma0 > 0.0 ? sqrt(gn / S.cg_gamma0) : 0.0);
+    if (!(S.lin_rel > tol) || S.lin_it >= maxit) {
         S.lin_active = 0;
         if (S.lin_rel > S.lin_maxrel) S.lin_maxrel = S.lin_rel;
     }
-    S.lin_prev = nr;
 }
 
 // After k_dmu_ceiling: the step ceiling (F2:383-391) and the start of the Armijo loop.
@@ -936,7 +1008,7 @@ __global__ void k_fin_mass(TrajState *st, const double *__restrict__ part, int n
 //   mode 1: partial slot  {sum rhs^2}, constant-coefficient operator (D = 0)     (B2:184)
 //   mode 2: partial slots {sum(.), sum rhs^2, min D, max D}, forward Schur operator
 __global__ void k_fin_lin_begin(TrajState *st, const double *__restrict__ part, int nblk, int mode,
-                                double tau, double kappa, double dt) {
+                                double tau, double kappa, double dt, double lin_tol) {
     const int b = blockIdx.x;
     TrajState &S = st[b];
     double v[NPART];
@@ -953,12 +1025,8 @@ __global__ void k_fin_lin_begin(TrajState *st, const double *__restrict__ part, 
     else { dmin = v[2]; dmax = v[3]; r0 = sqrt(v[1]); }
     S.Dmin = dmin;
     S.Dmax = dmax;
-    S.dbar = 0.5 * (dmin + dmax);
-    double den = mode == 2 ? S.dbar + 2.0 * sqrt(0.5 * kappa / dt)
-                           : tau + 0.5 * dt * S.dbar + 2.0 * sqrt(0.5 * dt);
-    double num = mode == 2 ? 0.5 * (dmax - dmin) : 0.25 * dt * (dmax - dmin);
-    S.rho = den > 0.0 ? num / den : 1.0;
-    S.theta = fmin(0.97, fmax(0.5, sqrt(S.rho)));
+    if (mode == 2) cg_setup(S, 2.0 * sqrt(0.5 * kappa / dt), 1.0, lin_tol);
+    else cg_setup(S, tau + 2.0 * sqrt(0.5 * dt), 0.5 * dt, lin_tol);
     S.lin_r0 = r0;
     S.lin_active = r0 > 0.0 ? 1 : 0;
     S.lin_it = 0;
@@ -1062,4 +1130,159 @@ __global__ __launch_bounds__(NTH) void k_ramp(Geom G, int tiles_f, const double 
             pq[b * hist_stride + (long)lvl * G.plane + o] = (1 - tp) * phi0[b * G.plane + o] + tp * phiT[b * G.plane + o];
         }
     }
+}
+
+
+// =================================================================================
+// Conjugate gradients on the preconditioned Schur / adjoint systems.
+//
+// Forward (left preconditioning):  T = P^-1 A,  A = I/dt + M (kappa/2 M + D) = P + M Delta,
+//   Delta = D - dbar > 0.  T is self-adjoint and positive in <x, y>_Z = sum W Delta x y, so
+//   plain CG applies with z = P^-1 (rhs - A x) as residual:
+//       v = A p; q = P^-1 v; alpha = <z,z>_Z / <p,q>_Z; x += alpha p; z -= alpha q;
+//       beta = <z',z'>_Z / <z,z>_Z; p = z' + beta p.
+// Adjoint (right preconditioning): A P^-1 is self-adjoint in <x, y>_Z' = sum W x y / Delta:
+//       pv = P^-1 ph; q = A pv; alpha = <r,r>_Z' / <ph,q>_Z'; x += alpha pv; r -= alpha q;
+//       beta = <r',r'>_Z' / <r,r>_Z'; ph = r' + beta ph.
+// =================================================================================
+
+// p_new = z + beta p_old (recomputed on the halo), v = A p_new.  FIRST: p_new = z.
+template <int FIRST>
+__global__ __launch_bounds__(NTH) void k_schur_p(Geom G, Phys P, const TrajState *__restrict__ st,
+                                                 long slot_stride, const double *__restrict__ z,
+                                                 const double *__restrict__ p_old, const double *__restrict__ D_s,
+                                                 double dt, double *__restrict__ p_new, double *__restrict__ v) {
+    TILE_COORDS;
+    const TrajState S = st[b];
+    if (!S.lin_active) return;
+    __shared__ double sx[(TY + 4) * (TX + 4)];
+    __shared__ double stt[(TY + 2) * (TX + 2)];
+    constexpr int W2 = TX + 4, W1 = TX + 2;
+    const long pb = b * G.plane;
+    if (FIRST) load_tile<2>(sx, z + pb, G, c0, r0);
+    else load_tile_axpy<2>(sx, z + pb, p_old + pb, S.cg_beta, G, c0, r0);
+    __syncthreads();
+    const double *Dp = D_s + S.slot * slot_stride + pb;
+    for (int e = threadIdx.x; e < (TY + 2) * W1; e += NTH) {
+        int ly = e / W1, lxx = e - ly * W1;
+        int gr = refl(r0 - 1 + ly, G.ns), gc = refl(c0 - 1 + lxx, G.nf);
+        int p2 = (ly + 1) * W2 + lxx + 1;
+        stt[e] = -0.5 * P.kappa * lap_at<W2>(sx, p2, G.ax, G.ay) + Dp[(long)gr * G.pitch + gc] * sx[p2];
+    }
+    __syncthreads();
+    const double idt = 1.0 / dt;
+    for (int k = 0; k < TY / 4; ++k) {
+        int ly = ly0 + 4 * k, r = r0 + ly, c = c0 + lx;
+        if (r < G.ns && c < G.nf) {
+            int p1 = (ly + 1) * W1 + lx + 1, p2 = (ly + 2) * W2 + lx + 2;
+            long o = pb + (long)r * G.pitch + c;
+            p_new[o] = sx[p2];
+            v[o] = sx[p2] * idt - lap_at<W1>(stt, p1, G.ax, G.ay);
+        }
+    }
+}
+
+// x (+)= alpha p; z -= alpha q; partial sum W (D - dbar) z^2.
+template <int FIRST>
+__global__ __launch_bounds__(NTH) void k_cg_update(Geom G, const TrajState *__restrict__ st, long slot_stride,
+                                                   const double *__restrict__ p, const double *__restrict__ q,
+                                                   const double *__restrict__ D_s, double *__restrict__ x,
+                                                   double *__restrict__ z, double *__restrict__ part) {
+    TILE_COORDS;
+    const TrajState S = st[b];
+    if (!S.lin_active) return;
+    __shared__ double sred[NPART * 4];
+    const long pb = b * G.plane;
+    double acc[1] = {0.0};
+    for (int k = 0; k < TY / 4; ++k) {
+        int r = r0 + ly0 + 4 * k, c = c0 + lx;
+        if (r < G.ns && c < G.nf) {
+            long o = pb + (long)r * G.pitch + c;
+            double xn = S.cg_alpha * p[o];
+            if (!FIRST) xn += x[o];
+            x[o] = xn;
+            double zn = z[o] - S.cg_alpha * q[o];
+            z[o] = zn;
+            acc[0] += wdev(r, c, G) * (D_s[S.slot * slot_stride + o] - S.dbar) * (zn * zn);
+        }
+    }
+    const int op[1] = {0};
+    block_reduce_store<1>(acc, op, sred, part + ((long)b * nblk + blk) * NPART);
+}
+
+// ph = r + beta ph (FIRST: ph = r)
+template <int FIRST>
+__global__ __launch_bounds__(NTH) void k_cg_dir(Geom G, const TrajState *__restrict__ st,
+                                                const double *__restrict__ r, double *__restrict__ ph) {
+    TILE_COORDS;
+    const TrajState S = st[b];
+    if (!S.lin_active) return;
+    for (int k = 0; k < TY / 4; ++k) {
+        int rr = r0 + ly0 + 4 * k, c = c0 + lx;
+        if (rr < G.ns && c < G.nf) {
+            long o = b * G.plane + (long)rr * G.pitch + c;
+            ph[o] = FIRST ? r[o] : r[o] + S.cg_beta * ph[o];
+        }
+    }
+}
+
+// q = A(phi_n) pv with partial sum W ph q / (D_n - dbar)
+__global__ __launch_bounds__(NTH) void k_adj_q(Geom G, Phys P, const TrajState *__restrict__ st,
+                                               const double *__restrict__ pv, const double *__restrict__ Dn,
+                                               const double *__restrict__ ph, double dt, double *__restrict__ q,
+                                               double *__restrict__ part) {
+    TILE_COORDS;
+    const TrajState S = st[b];
+    if (!S.lin_active) return;
+    __shared__ double sx[(TY + 4) * (TX + 4)];
+    __shared__ double stt[(TY + 2) * (TX + 2)];
+    __shared__ double sred[NPART * 4];
+    constexpr int W2 = TX + 4, W1 = TX + 2;
+    const long pb = b * G.plane;
+    load_tile<2>(sx, pv + pb, G, c0, r0);
+    __syncthreads();
+    for (int e = threadIdx.x; e < (TY + 2) * W1; e += NTH) {
+        int ly = e / W1, lxx = e - ly * W1;
+        stt[e] = -lap_at<W2>(sx, (ly + 1) * W2 + lxx + 1, G.ax, G.ay);
+    }
+    __syncthreads();
+    double acc[1] = {0.0};
+    for (int k = 0; k < TY / 4; ++k) {
+        int ly = ly0 + 4 * k, r = r0 + ly, c = c0 + lx;
+        if (r < G.ns && c < G.nf) {
+            int p1 = (ly + 1) * W1 + lx + 1, p2 = (ly + 2) * W2 + lx + 2;
+            long o = pb + (long)r * G.pitch + c;
+            double d = Dn[o];
+            double qv = sx[p2] + (P.tau + 0.5 * dt * d) * stt[p1] - 0.5 * dt * lap_at<W1>(stt, p1, G.ax, G.ay);
+            q[o] = qv;
+            acc[0] += wdev(r, c, G) / (d - S.dbar) * (ph[o] * qv);
+        }
+    }
+    const int op[1] = {0};
+    block_reduce_store<1>(acc, op, sred, part + ((long)b * nblk + blk) * NPART);
+}
+
+// x += alpha pv; r -= alpha q; partials: sum W r^2/(D_n - dbar), sum r^2
+__global__ __launch_bounds__(NTH) void k_cg_update_adj(Geom G, const TrajState *__restrict__ st,
+                                                       const double *__restrict__ pv, const double *__restrict__ q,
+                                                       const double *__restrict__ Dn, double *__restrict__ x,
+                                                       double *__restrict__ r, double *__restrict__ part) {
+    TILE_COORDS;
+    const TrajState S = st[b];
+    if (!S.lin_active) return;
+    __shared__ double sred[NPART * 4];
+    double acc[2] = {0.0, 0.0};
+    for (int k = 0; k < TY / 4; ++k) {
+        int rr = r0 + ly0 + 4 * k, c = c0 + lx;
+        if (rr < G.ns && c < G.nf) {
+            long o = b * G.plane + (long)rr * G.pitch + c;
+            x[o] += S.cg_alpha * pv[o];
+            double rn = r[o] - S.cg_alpha * q[o];
+            r[o] = rn;
+            acc[0] += wdev(rr, c, G) / (Dn[o] - S.dbar) * (rn * rn);
+            acc[1] += rn * rn;
+        }
+    }
+    const int op[2] = {0, 0};
+    block_reduce_store<2>(acc, op, sred, part + ((long)b * nblk + blk) * NPART);
 }
