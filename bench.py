@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py — PGD iterations/sec of the MI355X-native viscous Cahn–Hilliard optimal-control
+engine on the headline workload of BASELINE.json: 2D 512x512 grid, 1000 Crank–Nicolson time
+steps, batch of 64 random initial conditions sharded over 8 GPUs = 8 trajectories per GPU
+(weak scaling: the per-GPU batch is fixed as N grows).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one proximal-gradient iteration for every trajectory of the batch = one pass of
+the reference's loop body (GD2_configured.py:295-382): adjoint sweep (1000 linear solves) +
+gradient/soft-threshold prox + forward march (1000 Newton solves) + cost (+ backtracking
+forwards when the optimistic step fails).  Inputs are resident in HBM when the timed region
+starts.  `value` = trajectory-iterations per second over all ranks.
+
+The one collective of the data path is a single RCCL all-reduce of the cost scalars per step
+(10*B doubles); trajectories are independent.
+
+One JSON line is printed by rank 0.  Extra objects:
+  roofline      in-situ HIP-event timing of the dominant kernel class (one extra, untimed PGD
+                iteration with an event pair around each launch of the profiled kernels)
+  cpu_baseline  the CPU oracle (numpy/scipy restatement of the reference, SuperLU solves) timed
+                on this box's host cores on a bounded sample of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_MFMA_PEAK_TF = 78.6     # = 1/2 of the 157.3 TF FP32 vector/matrix peak of the same table
+                             # (v_mfma_f64_16x16x4_f64 issues at the FP64 vector rate on gfx950)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--grid", type=int, default=512, help="Nx = Ny")
+    ap.add_argument("--time-steps", type=int, default=1000)
+    ap.add_argument("--batch-per-gpu", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-grid", type=int, default=None, help="grid of the CPU sample (default: --grid)")
+    return ap.parse_args()
+
+
+def cpu_baseline(N, dt, M):
+    """Bounded CPU sample with the oracle (kind 'port'): at the full spatial size, one adjoint
+    time step (assemble + SuperLU solve of A(phi_n)) and one Newton linear solve of a forward
+    step (assemble + SuperLU solve of the 2x2-block Jacobian), single trajectory; a PGD
+    iteration is extrapolated linearly in the step count with 2 Newton solves per forward step
+    (the reference's own count at 512^2, tests/golden/g2d_newton_512.npz)."""
+    import scipy.sparse as sp
+    from scipy.sparse.linalg import spsolve
+    from oracle import vch2d_oracle as O2
+    P = O2.Params2D(Nx=N, Ny=N, T=dt * M, dt_initial=dt)
+    h = 1.0 / N
+    phi = O2.init_phi_random(N, N, 1e-2, amp=0.1, seed=42)
+    w = np.zeros_like(phi)
+    t0 = time.perf_counter()
+    L = O2.lap_matrix(N, N, h, h)
+    mu = O2.mu_init(phi, w, P, h, h)
+    Rp = O2.residual_phi(phi, phi, mu, mu, w, w, dt, P, h, h)
+    Rm = O2.residual_mu(phi, phi, mu, mu, dt, h, h)
+    J = O2.jac_matrix(phi, dt, P, L)
+    spsolve(J.tocsc(), -np.concatenate([Rp.ravel(), Rm.ravel()]))
+    t_newton = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    n = phi.size
+    I = sp.identity(n, format="csr")
+    LL = (L @ L).tocsr()
+    Dn = sp.diags(O2.fpp(phi.ravel(), P.c1, P.c2), 0, format="csr")
+    A = (I - P.tau * L + 0.5 * dt * LL - 0.5 * dt * (Dn @ L)).tocsc()
+    Bm = (I - P.tau * L - 0.5 * dt * LL + 0.5 * dt * (Dn @ L)).tocsr()
+    spsolve(A, Bm @ phi.ravel())
+    t_adj = time.perf_counter() - t0
+    solves_per_step = 2.0
+    per_iter = M * (t_adj + solves_per_step * t_newton)
+    return dict(value=1.0 / per_iter, unit="PGD iterations/s", cores=1, kind="port",
+                sample=(f"oracle (scipy SuperLU, serial) at {N}x{N}: 1 Newton linear solve {t_newton:.1f} s + "
+                        f"1 adjoint step {t_adj:.1f} s, 1 trajectory; extrapolated to {M} steps x "
+                        f"(1 adjoint + {solves_per_step:g} Newton solves)"),
+                newton_solve_s=t_newton, adjoint_step_s=t_adj)
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if a.gpus > 1 or world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    import vch_amd
+    from oracle import vch2d_oracle as O2     # init_phi_random only (seeded initial data + targets)
+
+    vch_amd.build()
+    N, M, B = a.grid, a.time_steps, a.batch_per_gpu
+    T = 1.0
+    dt = T / M
+    t_hist, dts = vch_amd.time_grid(T, dt)
+    M = len(dts)
+    eng = vch_amd.Engine2D(Nx=N, Ny=N, batch=B, max_steps=M, device=local)
+    seeds = [42 + rank * B + i for i in range(B)]
+    phi0 = np.stack([O2.init_phi_random(N, N, 1e-2, amp=0.1, seed=s) for s in seeds])
+    xs = np.linspace(0.0, 1.0, N + 1)
+    phi_T = 0.7 * np.sin(2 * np.pi * xs)[:, None] * np.cos(np.pi * xs)[None, :]       # G2:199
+    opt = vch_amd.make_opt()
+    t_init = time.perf_counter()
+    J0 = eng.pgd_init(phi0, np.broadcast_to(phi_T, phi0.shape).copy(), t_hist, opt, ramp=True, T=T)
+    t_init = time.perf_counter() - t_init
+
+    def allreduce_cost(J):
+        if dist is None:
+            return J.sum(axis=0)
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(J.sum(axis=0))).cuda()
+        dist.all_reduce(t)                      # the single RCCL collective of an iteration
+        return t.cpu().numpy()
+
+    def sync():
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    costs = []
+    for _ in range(a.warmup):
+        r = eng.pgd_iterate(1)
+        allreduce_cost(r["cost"])
+    sync()
+    t0 = time.perf_counter()
+    buckets = {}
+    attempts = 0
+    for _ in range(a.steps):
+        r = eng.pgd_iterate(1)                  # synchronous: returns when the device is done
+        Jsum = allreduce_cost(r["cost"])
+        costs.append(float(np.asarray(Jsum).ravel()[0]))
+        attempts += int(r["attempts"].sum())
+        for k, v in r["seconds"].items():
+            buckets[k] = buckets.get(k, 0.0) + float(v)
+    sync()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    total_traj = B * max(world, 1)
+    value = a.steps * total_traj / el
+
+    roof = None
+    extra = {}
+    if rank == 0 and not a.no_roofline:
+        eng.prof_begin(400000)
+        eng.pgd_iterate(1)
+        prof = eng.prof_end()
+        nodes = (N + 1) * (N + 1) * B
+        alg = {  # algorithmic bytes / flops per launch
+            "schur_p": ("hbm", 40.0 * nodes), "adj_q": ("hbm", 32.0 * nodes), "residual": ("hbm", 88.0 * nodes),
+            "cg_update": ("hbm", 48.0 * nodes), "adj_rhs": ("hbm", 72.0 * nodes),
+            "gemm": ("mfma", 2.0 * (N + 1) ** 3 * B),
+        }
+        tot = {k: v["ms"] for k, v in prof.items()}
+        dom = max(tot, key=tot.get)
+        extra["kernel_time_ms"] = {k: round(v["ms"], 3) for k, v in prof.items()}
+        extra["kernel_launches"] = {k: v["launches"] for k, v in prof.items()}
+
+        def roof_of(k):
+            kind, per = alg[k]
+            avg_s = prof[k]["ms"] * 1e-3 / max(prof[k]["launches"], 1)
+            if kind == "hbm":
+                ach = per / avg_s / 1e9
+                return dict(kernel=k, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
+                            frac=ach / HBM_PEAK_GBS, traffic=None, avg_us=avg_s * 1e6,
+                            launches=prof[k]["launches"], algorithmic_bytes_per_launch=per)
+            ach = per / avg_s / 1e12
+            return dict(kernel=k, bound="mfma", achieved=ach, peak=FP64_MFMA_PEAK_TF, unit="TFLOP/s",
+                        frac=ach / FP64_MFMA_PEAK_TF, traffic=None, avg_us=avg_s * 1e6,
+                        launches=prof[k]["launches"], algorithmic_flops_per_launch=per)
+        roof = roof_of(dom if dom in alg else "schur_p")
+        extra["roofline_newton_stencil"] = roof_of("schur_p")
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(a.cpu_grid or N, dt, M)
+
+    if rank == 0:
+        out = {
+            "metric": "PGD iterations/sec (fwd Newton + adjoint + prox), 2D 512^2 grid",
+            "value": value, "unit": "PGD iterations/s", "n_gpus": max(world, 1), "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": 1e3 * el / a.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"2D {N}x{N}, {M} time steps, batch {B} trajectories per GPU "
+                                   f"({total_traj} total), seeds 42+i, targets build_targets 1/1, u0 = 0",
+                       "grid": N, "time_steps": M, "batch_per_gpu": B, "parallelism": f"batch-shard x{max(world, 1)}"},
+            "roofline": roof, "cpu_baseline": cpu,
+            "init_s": t_init, "J0_sum": float(J0[:, 4].sum()), "cost_sum_per_step": costs,
+            "backtracking_forwards": attempts, "time_buckets_s": buckets,
+        }
+        out.update(extra)
+        print(json.dumps(out))
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

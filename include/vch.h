@@ -189,6 +189,16 @@ int vch2d_pgd_cost_dev(vch2d_ctx *ctx, double **ptr_dev);
 
 #define VCH_RESIDENT ((const double *)(uintptr_t)1)
 
+/* -- in-situ kernel timing (used by bench.py for the roofline figure; no reference counterpart) --
+ * Between _begin and _end every launch of the profiled kernel classes is bracketed by a HIP event
+ * pair on the engine's stream (at most max_launches pairs).  _end returns, per class, the summed
+ * elapsed milliseconds and the number of launches:
+ *   0 Newton stencil SpMV (k_schur_p)  1 DCT GEMM  2 Newton residual  3 adjoint operator
+ *   4 CG vector update  5 adjoint right-hand side  6 cost integrands  7 gradient+prox */
+#define VCH_PROF_CLASSES 8
+int vch2d_prof_begin(vch2d_ctx *ctx, int max_launches);
+int vch2d_prof_end(vch2d_ctx *ctx, double *ms_out, int64_t *count_out, int ncls);
+
 #ifdef __cplusplus
 }
 #endif

@@ -105,6 +105,8 @@ SIGNATURES = {
     "vch2d_pgd_iterate": (C.c_int, [_P, C.c_int, _D, _D, _I32, _D, _D]),
     "vch2d_pgd_get": (C.c_int, [_P, C.c_int, _D]),
     "vch2d_pgd_cost_dev": (C.c_int, [_P, C.POINTER(C.c_void_p)]),
+    "vch2d_prof_begin": (C.c_int, [_P, C.c_int]),
+    "vch2d_prof_end": (C.c_int, [_P, _D, C.POINTER(C.c_int64), C.c_int]),
 }
 
 _lib = None

@@ -63,6 +63,11 @@ struct vch2d_ctx {
     std::vector<int> pgd_plateau, pgd_done, pgd_k;
     std::vector<std::vector<double>> pgd_cost_hist;
     double *J_dev;
+    // per-kernel-class HIP-event timing (bench.py roofline leg)
+    bool prof_on;
+    std::vector<hipEvent_t> prof_ev;
+    std::vector<int> prof_cls;
+    size_t prof_used;
     // knobs
     int lin_maxit;
     double lin_tol;
@@ -74,6 +79,27 @@ struct vch2d_ctx {
         hipError_t e_ = hipGetLastError();                                         \
         if (e_ != hipSuccess)                                                      \
             return vch_fail(VCH_ERR_HIP, "launch %s: %s", #kern, hipGetErrorString(e_)); \
+    } while (0)
+
+// Kernel classes for the in-situ timing of vch2d_prof_begin/_end.
+enum { PC_SCHUR_P = 0, PC_GEMM = 1, PC_RESIDUAL = 2, PC_ADJ_Q = 3, PC_CG_UPDATE = 4, PC_ADJ_RHS = 5, PC_COST = 6,
+       PC_PROX = 7, PC_NCLS = 8 };
+
+// launch with an event pair around it when profiling is on (events are recorded on the
+// engine's own stream, the one the kernel is launched on)
+#define LAUNCHC(cls, kern, grid, block, ...)                                                    \
+    do {                                                                                        \
+        const bool rec_ = c->prof_on && c->prof_used + 2 <= c->prof_ev.size();                  \
+        if (rec_) hipEventRecord(c->prof_ev[c->prof_used], c->stream);                          \
+        hipLaunchKernelGGL(kern, grid, block, 0, c->stream, __VA_ARGS__);                       \
+        if (rec_) {                                                                             \
+            hipEventRecord(c->prof_ev[c->prof_used + 1], c->stream);                            \
+            c->prof_cls.push_back(cls);                                                         \
+            c->prof_used += 2;                                                                  \
+        }                                                                                       \
+        hipError_t e_ = hipGetLastError();                                                      \
+        if (e_ != hipSuccess)                                                                   \
+            return vch_fail(VCH_ERR_HIP, "launch %s: %s", #kern, hipGetErrorString(e_));        \
     } while (0)
 
 static int dalloc(double **p, size_t n, hipStream_t s) {
@@ -185,6 +211,8 @@ extern "C" vch2d_ctx *vch2d_create(const vch2d_params *p, int batch, int max_ste
     c->M_res = -1;
     c->u_rows_res = 0;
     c->pgd_ready = false;
+    c->prof_on = false;
+    c->prof_used = 0;
     c->lin_maxit = 4000;
     c->lin_tol = 1e-15;
     auto fail = [&](const char *what) {
@@ -259,6 +287,7 @@ extern "C" void vch2d_destroy(vch2d_ctx *c) {
     hipHostFree(c->st_host);
     hipHostFree(c->hist_host);
     if (c->cost_lvl_host) hipHostFree(c->cost_lvl_host);
+    for (hipEvent_t e : c->prof_ev) hipEventDestroy(e);
     hipEventDestroy(c->ev0);
     hipEventDestroy(c->ev1);
     hipStreamDestroy(c->stream);
@@ -289,20 +318,20 @@ static int precond(vch2d_ctx *c, const double *in, long in_slot_stride, double *
     dim3 g((nf + GN - 1) / GN, (ns + GM - 1) / GM, c->B);
     SpecArgs sp{c0, c1a, c1b, c2, c->ms, c->mf, other, c->D_s, c->slot_stride, c->gpart};
     // T1 = g Q1f
-    LAUNCH((k_gemm<false, 0>), g, dim3(256), ns, nf, nf, in, (long)G.pitch, G.plane, in_slot_stride, c->Q1f, (long)nf, 0L,
+    LAUNCHC(PC_GEMM, (k_gemm<false, 0>), g, dim3(256), ns, nf, nf, in, (long)G.pitch, G.plane, in_slot_stride, c->Q1f, (long)nf, 0L,
            c->t1, (long)G.pitch, G.plane, sp, c->st, gate);
     // T2 = (Q1s^T T1) o mult
-    LAUNCH((k_gemm<true, 1>), g, dim3(256), ns, nf, ns, c->Q1s, (long)ns, 0L, 0L, c->t1, (long)G.pitch, G.plane, c->t2,
+    LAUNCHC(PC_GEMM, (k_gemm<true, 1>), g, dim3(256), ns, nf, ns, c->Q1s, (long)ns, 0L, 0L, c->t1, (long)G.pitch, G.plane, c->t2,
            (long)G.pitch, G.plane, sp, c->st, gate);
     // T3 = Q2s^T T2
-    LAUNCH((k_gemm<true, 0>), g, dim3(256), ns, nf, ns, c->Q2s, (long)ns, 0L, 0L, c->t2, (long)G.pitch, G.plane, c->t1,
+    LAUNCHC(PC_GEMM, (k_gemm<true, 0>), g, dim3(256), ns, nf, ns, c->Q2s, (long)ns, 0L, 0L, c->t2, (long)G.pitch, G.plane, c->t1,
            (long)G.pitch, G.plane, sp, c->st, gate);
     // out = T3 Q2f
     if (last == 3)
-        LAUNCH((k_gemm<false, 3>), g, dim3(256), ns, nf, nf, c->t1, (long)G.pitch, G.plane, 0L, c->Q2f, (long)nf, 0L, out,
+        LAUNCHC(PC_GEMM, (k_gemm<false, 3>), g, dim3(256), ns, nf, nf, c->t1, (long)G.pitch, G.plane, 0L, c->Q2f, (long)nf, 0L, out,
                (long)G.pitch, G.plane, sp, c->st, gate);
     else
-        LAUNCH((k_gemm<false, 0>), g, dim3(256), ns, nf, nf, c->t1, (long)G.pitch, G.plane, 0L, c->Q2f, (long)nf, 0L, out,
+        LAUNCHC(PC_GEMM, (k_gemm<false, 0>), g, dim3(256), ns, nf, nf, c->t1, (long)G.pitch, G.plane, 0L, c->Q2f, (long)nf, 0L, out,
                (long)G.pitch, G.plane, sp, c->st, gate);
     return 0;
 }
@@ -340,16 +369,16 @@ static int schur_solve(vch2d_ctx *c, double dt, int budget) {
         for (int j = 0; j < chunk; ++j, ++done) {
             double *pn = c->cg_p[done & 1], *po = c->cg_p[(done + 1) & 1];
             if (done == 0) {
-                LAUNCH((k_schur_p<1>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, z, po, c->D_s, dt, pn, c->cg_v);
+                LAUNCHC(PC_SCHUR_P, (k_schur_p<1>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, z, po, c->D_s, dt, pn, c->cg_v);
             } else {
-                LAUNCH((k_schur_p<0>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, z, po, c->D_s, dt, pn, c->cg_v);
+                LAUNCHC(PC_SCHUR_P, (k_schur_p<0>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, z, po, c->D_s, dt, pn, c->cg_v);
             }
             VCHCHK(precond(c, c->cg_v, 0, c->cg_q, 3, pn, c0, 0.0, 1.0, c2, 1));           // q = P^-1 A p, <p,q>_Z
             LAUNCH(k_fin_cg_alpha, dim3(c->B), dim3(64), c->st, c->gpart, c->gnblk, 1, 0);
             if (done == 0) {
-                LAUNCH((k_cg_update<1>), c->grid, dim3(NTH), c->G, c->st, c->slot_stride, pn, c->cg_q, c->D_s, c->x, z, c->part);
+                LAUNCHC(PC_CG_UPDATE, (k_cg_update<1>), c->grid, dim3(NTH), c->G, c->st, c->slot_stride, pn, c->cg_q, c->D_s, c->x, z, c->part);
             } else {
-                LAUNCH((k_cg_update<0>), c->grid, dim3(NTH), c->G, c->st, c->slot_stride, pn, c->cg_q, c->D_s, c->x, z, c->part);
+                LAUNCHC(PC_CG_UPDATE, (k_cg_update<0>), c->grid, dim3(NTH), c->G, c->st, c->slot_stride, pn, c->cg_q, c->D_s, c->x, z, c->part);
             }
             LAUNCH(k_fin_cg_beta, dim3(c->B), dim3(64), c->st, c->part, c->nblk, 0, c->lin_tol, c->lin_maxit, 0);
         }
@@ -368,7 +397,7 @@ static int newton_level(vch2d_ctx *c, double dt, const double *un, const double 
     LAUNCH(k_prepare, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s, c->w, un, unp1, u_stride,
            wnew_in, dt, c->wnew, c->mu0, c->cphi, c->cmu);
     LAUNCH(k_fin_newton_begin, dim3(c->B), dim3(64), c->st);
-    LAUNCH((k_residual<0>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s, c->Rphi_s, c->rhs_s,
+    LAUNCHC(PC_RESIDUAL, (k_residual<0>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s, c->Rphi_s, c->rhs_s,
            c->D_s, c->mu0, c->x, c->dmu, c->cphi, c->cmu, dt, c->part);
     LAUNCH((k_fin_residual<0>), dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->hist_dev, c->P.kappa, dt, c->lin_tol);
     VCHCHK(sync_state(c));
@@ -391,7 +420,7 @@ static int newton_level(vch2d_ctx *c, double dt, const double *un, const double 
         LAUNCH(k_fin_ceiling, dim3(c->B), dim3(64), c->st, c->part, c->nblk);
         int tguard = 0;
         do {
-            LAUNCH((k_residual<1>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s, c->Rphi_s,
+            LAUNCHC(PC_RESIDUAL, (k_residual<1>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s, c->Rphi_s,
                    c->rhs_s, c->D_s, c->mu0, c->x, c->dmu, c->cphi, c->cmu, dt, c->part);
             LAUNCH((k_fin_residual<1>), dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->hist_dev, c->P.kappa, dt, c->lin_tol);
             VCHCHK(sync_state(c));
@@ -567,9 +596,9 @@ static int adjoint_solve_cg(vch2d_ctx *c, double dt, int budget) {
             if (done == 0) LAUNCH((k_cg_dir<1>), c->grid, dim3(NTH), c->G, c->st, c->r, ph);
             else LAUNCH((k_cg_dir<0>), c->grid, dim3(NTH), c->G, c->st, c->r, ph);
             VCHCHK(precond(c, ph, 0, pv, 0, nullptr, 1.0, c->P.tau, 0.5 * dt, 0.5 * dt, 1));
-            LAUNCH(k_adj_q, c->grid, dim3(NTH), c->G, c->P, c->st, pv, c->cmu, ph, dt, q, c->part);
+            LAUNCHC(PC_ADJ_Q, k_adj_q, c->grid, dim3(NTH), c->G, c->P, c->st, pv, c->cmu, ph, dt, q, c->part);
             LAUNCH(k_fin_cg_alpha, dim3(c->B), dim3(64), c->st, c->part, c->nblk, NPART, 0);
-            LAUNCH(k_cg_update_adj, c->grid, dim3(NTH), c->G, c->st, pv, q, c->cmu, c->x, c->r, c->part);
+            LAUNCHC(PC_CG_UPDATE, k_cg_update_adj, c->grid, dim3(NTH), c->G, c->st, pv, q, c->cmu, c->x, c->r, c->part);
             LAUNCH(k_fin_cg_beta, dim3(c->B), dim3(64), c->st, c->part, c->nblk, 1, c->lin_tol, c->lin_maxit, 0);
         }
         if (done < budget) {
@@ -746,7 +775,7 @@ static int backward_core(vch2d_ctx *c, const double *phi_hist_dev, int M, const 
             if (ql) LAUNCH(k_copy_plane, c->grid, dim3(NTH), G, q_out + (long)(n + 1) * G.plane, hs, ql, hs);
             continue;
         }
-        LAUNCH(k_adj_rhs, c->grid, dim3(NTH), G, c->P, c->x, qa, phi_hist_dev + (long)n * G.plane,
+        LAUNCHC(PC_ADJ_RHS, k_adj_rhs, c->grid, dim3(NTH), G, c->P, c->x, qa, phi_hist_dev + (long)n * G.plane,
                phi_hist_dev + (long)(n + 1) * G.plane, phiQ_dev ? phiQ_dev + (long)n * G.plane : (const double *)nullptr,
                phiQ_dev ? phiQ_dev + (long)(n + 1) * G.plane : (const double *)nullptr, hs, dtn, b1, rhs, Dn, c->part);
         LAUNCH(k_fin_lin_begin, dim3(c->B), dim3(64), c->st, c->part, c->nblk, 0, c->P.tau, c->P.kappa, dtn, c->lin_tol);
@@ -847,7 +876,7 @@ static int cost_core(vch2d_ctx *c, const double *phi_dev, const double *u_dev, c
         HIPCHK(hipHostMalloc((void **)&c->cost_lvl_host, (size_t)c->B * (c->Mmax + 1) * 4 * 8));
     }
     dim3 g(ntiles, levels, c->B);
-    LAUNCH(k_cost, g, dim3(NTH), G, G.tiles_f, phi_dev, u_dev, pq_dev, pt_dev, (const double *)c->phi0,
+    LAUNCHC(PC_COST, k_cost, g, dim3(NTH), G, G.tiles_f, phi_dev, u_dev, pq_dev, pt_dev, (const double *)c->phi0,
            (const double *)((ramp && !pq_dev) ? c->tfrac_dev : nullptr), hist_stride(c), M, (const double *)c->W_cost,
            c->cost_part);
     LAUNCH(k_cost_fin, dim3(c->B * levels), dim3(64), ntiles, (const double *)c->cost_part, c->cost_lvl);
@@ -922,7 +951,7 @@ static int grad_prox_core(vch2d_ctx *c, const double *u_dev, const double *r_dev
     }
     dim3 g(c->nblk, rows, c->B);
     HIPCHK(hipMemsetAsync(c->cost_part, 0, (size_t)c->B * rows * c->nblk * 4 * 8, c->stream));
-    LAUNCH(k_grad_prox, g, dim3(NTH), c->G, c->G.tiles_f, u_dev, r_dev, hist_stride(c), (const double *)c->alpha_dev, o->b3,
+    LAUNCHC(PC_PROX, k_grad_prox, g, dim3(NTH), c->G, c->G.tiles_f, u_dev, r_dev, hist_stride(c), (const double *)c->alpha_dev, o->b3,
            o->kappa_sparsity, o->u_min, o->u_max, uout_dev, c->cost_part);
     if (change_out) {
         LAUNCH(k_cost_fin, dim3(c->B * rows), dim3(64), c->nblk, (const double *)c->cost_part, c->cost_lvl);
@@ -1146,4 +1175,36 @@ extern "C" int vch2d_pgd_cost_dev(vch2d_ctx *c, double **ptr_dev) {
     if (!c->pgd_ready) return vch_fail(VCH_ERR_STATE, "vch2d_pgd_cost_dev: call vch2d_pgd_init first");
     *ptr_dev = c->J_dev;
     return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// in-situ kernel timing (HIP events on the engine stream) for bench.py's roofline leg
+// ------------------------------------------------------------------------------------
+extern "C" int vch2d_prof_begin(vch2d_ctx *c, int max_launches) {
+    CTXCHK(c);
+    ARGCHK(max_launches >= 1, "max_launches must be >= 1");
+    while (c->prof_ev.size() < (size_t)2 * max_launches) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        c->prof_ev.push_back(e);
+    }
+    c->prof_used = 0;
+    c->prof_cls.clear();
+    c->prof_on = true;
+    return 0;
+}
+
+extern "C" int vch2d_prof_end(vch2d_ctx *c, double *ms_out, int64_t *count_out, int ncls) {
+    CTXCHK(c);
+    ARGCHK(ms_out && count_out && ncls >= 1, "NULL output");
+    c->prof_on = false;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < ncls; ++k) { ms_out[k] = 0.0; count_out[k] = 0; }
+    for (size_t i = 0; i < c->prof_cls.size(); ++i) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, c->prof_ev[2 * i], c->prof_ev[2 * i + 1]));
+        int k = c->prof_cls[i];
+        if (k < ncls) { ms_out[k] += ms; count_out[k]++; }
+    }
+    return (int)c->prof_cls.size();
 }

@@ -292,3 +292,16 @@ class Engine2D:
         p = C.c_void_p()
         check(self.lib.vch2d_pgd_cost_dev(self.ctx, C.byref(p)))
         return p.value
+
+    # -- in-situ kernel timing -------------------------------------------------------------
+    PROF_CLASSES = ("schur_p", "gemm", "residual", "adj_q", "cg_update", "adj_rhs", "cost", "prox")
+
+    def prof_begin(self, max_launches=200000):
+        check(self.lib.vch2d_prof_begin(self.ctx, int(max_launches)))
+
+    def prof_end(self):
+        n = len(self.PROF_CLASSES)
+        ms = np.zeros(n)
+        cnt = np.zeros(n, dtype=np.int64)
+        check(self.lib.vch2d_prof_end(self.ctx, _dp(ms), cnt.ctypes.data_as(C.POINTER(C.c_int64)), n))
+        return {k: dict(ms=float(ms[i]), launches=int(cnt[i])) for i, k in enumerate(self.PROF_CLASSES)}
