@@ -171,7 +171,8 @@ def main():
         alg = {  # algorithmic bytes / flops per launch
             "schur_p": ("hbm", 40.0 * nodes), "adj_q": ("hbm", 32.0 * nodes), "residual": ("hbm", 88.0 * nodes),
             "cg_update": ("hbm", 48.0 * nodes), "adj_rhs": ("hbm", 72.0 * nodes),
-            "gemm": ("mfma", 2.0 * (N + 1) ** 3 * B),
+            # DCT preconditioner: three FFT passes (field in, field out) or four MFMA f64 GEMMs
+            "dct": ("hbm", 16.0 * nodes) if eng.uses_fft else ("mfma", 2.0 * (N + 1) ** 3 * B),
         }
         tot = {k: v["ms"] for k, v in prof.items()}
         dom = max(tot, key=tot.get)
@@ -192,6 +193,7 @@ def main():
                         launches=prof[k]["launches"], algorithmic_flops_per_launch=per)
         roof = roof_of(dom if dom in alg else "schur_p")
         extra["roofline_newton_stencil"] = roof_of("schur_p")
+        extra["dct_path"] = "fft (in-LDS radix-4 Stockham)" if eng.uses_fft else "gemm (MFMA f64 16x16x4)"
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

@@ -76,6 +76,9 @@ typedef struct vch2d_ctx vch2d_ctx;
 vch2d_ctx *vch2d_create(const vch2d_params *p, int batch, int max_steps, int device);
 void vch2d_destroy(vch2d_ctx *ctx);
 int vch2d_batch(const vch2d_ctx *ctx);
+/* 1 when the DCT preconditioner runs as in-LDS FFTs (both Nx, Ny powers of two in 16..2048),
+ * 0 when it runs as MFMA f64 matrix products (any grid size). */
+int vch2d_uses_fft(const vch2d_ctx *ctx);
 
 /* -- discrete operators (kernel-level parity tests; each replaces one reference helper) -- */
 

@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libvch_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 SOURCES = ["vch_hip.hip"]
-DEPS = ["vch_hip.hip", "vch_engine2d.hip", "vch_kernels2d.h", "vch_gemm.h", "vch_common.h",
+DEPS = ["vch_hip.hip", "vch_engine2d.hip", "vch_kernels2d.h", "vch_gemm.h", "vch_fft.h", "vch_common.h",
         os.path.join(ROOT, "include", "vch.h")]
 
 
@@ -83,6 +83,7 @@ SIGNATURES = {
     "vch2d_create": (_P, [C.POINTER(Params2D), C.c_int, C.c_int, C.c_int]),
     "vch2d_destroy": (None, [_P]),
     "vch2d_batch": (C.c_int, [_P]),
+    "vch2d_uses_fft": (C.c_int, [_P]),
     "vch2d_apply_laplacian": (C.c_int, [_P, _D, _D]),
     "vch2d_initialize_mu": (C.c_int, [_P, _D, _D, _D]),
     "vch2d_solve_w": (C.c_int, [_P, _D, C.c_double, _D, _D, _D]),

@@ -6,6 +6,7 @@
 #include "vch_common.h"
 #include "vch_kernels2d.h"
 #include "vch_gemm.h"
+#include "vch_fft.h"
 #include <algorithm>
 #include <cmath>
 
@@ -44,6 +45,9 @@ struct vch2d_ctx {
     double *hist_dev, *hist_host;         // [B][HIST_CAP]
     // DCT-I matrices and eigenvalues
     double *Q1f, *Q2f, *Q1s, *Q2s, *mf, *ms;
+    bool use_fft;                         // both axes power-of-two: in-LDS FFT instead of the GEMMs
+    FftAxis fax, sax;
+    double2 *tw_f, *tw_s;
     // resident histories [B][Mmax+1][plane] (lazy)
     double *phi_hist, *u_hist, *u_trial, *phi_trial, *phiQ, *r_hist, *p_hist, *q_hist;
     double *phiT, *phi0;                  // [B][plane]
@@ -233,7 +237,7 @@ extern "C" vch2d_ctx *vch2d_create(const vch2d_params *p, int batch, int max_ste
     if (dalloc(&c->wts_mass, G.plane, c->stream) || dalloc(&c->W_cost, G.plane, c->stream)) return fail("hipMalloc");
     if (dalloc(&c->part, (size_t)batch * c->nblk * NPART, c->stream)) return fail("hipMalloc");
     c->gnblk = ((G.nf + GN - 1) / GN) * ((G.ns + GM - 1) / GM);
-    if (dalloc(&c->gpart, (size_t)batch * c->gnblk, c->stream)) return fail("hipMalloc");
+    if (dalloc(&c->gpart, (size_t)batch * (c->gnblk + G.ns), c->stream)) return fail("hipMalloc");
     if (dalloc(&c->hist_dev, (size_t)batch * HIST_CAP, c->stream)) return fail("hipMalloc");
     if (dalloc(&c->alpha_dev, batch, c->stream) || dalloc(&c->J_dev, 5 * (size_t)batch, c->stream)) return fail("hipMalloc");
     if (hipMalloc((void **)&c->st, sizeof(TrajState) * batch) != hipSuccess) return fail("hipMalloc");
@@ -268,6 +272,35 @@ extern "C" vch2d_ctx *vch2d_create(const vch2d_params *p, int batch, int max_ste
         dct_tables(p->Ny, c->hy, Q1, Q2, m);
         if (!up(&c->Q1s, Q1) || !up(&c->Q2s, Q2) || !up(&c->ms, m)) return fail("DCT table upload");
     }
+    // FFT plan (power-of-two grids)
+    {
+        auto pow2 = [](int n) { return n >= 16 && n <= 2048 && (n & (n - 1)) == 0; };
+        c->use_fft = pow2(p->Nx) && pow2(p->Ny) && getenv("VCH_FORCE_GEMM_DCT") == nullptr;
+        c->tw_f = c->tw_s = nullptr;
+        if (c->use_fft) {
+            auto mk = [&](int N, double2 **tw, FftAxis &ax) {
+                const int L = 2 * N;
+                std::vector<double2> t(L);
+                const long double pi = 3.14159265358979323846264338327950288L;
+                for (int m = 0; m < L; ++m) {
+                    long double a = -2.0L * pi * m / L;
+                    t[m] = make_double2((double)cosl(a), (double)sinl(a));
+                }
+                if (hipMalloc((void **)tw, sizeof(double2) * L) != hipSuccess) return false;
+                if (hipMemcpy(*tw, t.data(), sizeof(double2) * L, hipMemcpyHostToDevice) != hipSuccess) return false;
+                int lg = 0;
+                while ((1 << lg) < L) ++lg;
+                ax = FftAxis{N, L, lg, *tw};
+                return true;
+            };
+            if (!mk(p->Nx, &c->tw_f, c->fax) || !mk(p->Ny, &c->tw_s, c->sax)) return fail("FFT twiddle upload");
+            {
+                const int Cc = c->fax.L <= 1024 ? 1024 : c->fax.L;
+                const int rpw = 2 * (Cc >> c->fax.logL);
+                c->gnblk = (G.ns + rpw - 1) / rpw;
+            }
+        }
+    }
     if (hipStreamSynchronize(c->stream) != hipSuccess) return fail("hipStreamSynchronize");
     return c;
 }
@@ -284,6 +317,8 @@ extern "C" void vch2d_destroy(vch2d_ctx *c) {
     for (double *q : all)
         if (q) hipFree(q);
     hipFree(c->st);
+    if (c->tw_f) hipFree(c->tw_f);
+    if (c->tw_s) hipFree(c->tw_s);
     hipHostFree(c->st_host);
     hipHostFree(c->hist_host);
     if (c->cost_lvl_host) hipHostFree(c->cost_lvl_host);
@@ -317,6 +352,39 @@ static int precond(vch2d_ctx *c, const double *in, long in_slot_stride, double *
     const int ns = G.ns, nf = G.nf;
     dim3 g((nf + GN - 1) / GN, (ns + GM - 1) / GM, c->B);
     SpecArgs sp{c0, c1a, c1b, c2, c->ms, c->mf, other, c->D_s, c->slot_stride, c->gpart};
+    if (c->use_fft) {
+        const double scale = 1.0 / (4.0 * (double)c->fax.N * (double)c->sax.N);
+        // C = complex doubles per workgroup: 1024 (one wavefront) unless the FFT is longer
+#define DCT_ROWS(EPI_, C_, in_, iss_, out_)                                                                     \
+    do {                                                                                                        \
+        const int rpw = 2 * (C_ >> c->fax.logL);                                                                \
+        LAUNCHC(PC_GEMM, (k_dct_rows<EPI_, C_>), dim3((ns + rpw - 1) / rpw, 1, c->B), dim3(C_ / 16), G, c->fax, \
+                in_, iss_, out_, 1.0, sp, c->st, gate);                                                         \
+    } while (0)
+#define DCT_COLS(C_)                                                                                            \
+    do {                                                                                                        \
+        const int cpw = 2 * (C_ >> c->sax.logL);                                                                \
+        LAUNCHC(PC_GEMM, (k_dct_cols<C_>), dim3((nf + cpw - 1) / cpw, 1, c->B), dim3(C_ / 16), G, c->sax,       \
+                (const double *)c->t1, c->t2, scale, sp, c->st, gate);                                          \
+    } while (0)
+#define DCT_ROWS_ANY(EPI_, in_, iss_, out_)                                  \
+    do {                                                                     \
+        if (c->fax.L <= 1024) DCT_ROWS(EPI_, 1024, in_, iss_, out_);         \
+        else if (c->fax.L == 2048) DCT_ROWS(EPI_, 2048, in_, iss_, out_);    \
+        else DCT_ROWS(EPI_, 4096, in_, iss_, out_);                          \
+    } while (0)
+        DCT_ROWS_ANY(0, in, in_slot_stride, c->t1);
+        {
+            static const int colsC = getenv("VCH_DCT_COLS_C") ? atoi(getenv("VCH_DCT_COLS_C")) : 0;   // tuning knob
+            const int Cc = std::max(colsC ? colsC : 1024, c->sax.L);
+            if (Cc <= 1024) DCT_COLS(1024);
+            else if (Cc == 2048) DCT_COLS(2048);
+            else DCT_COLS(4096);
+        }
+        if (last == 3) DCT_ROWS_ANY(3, (const double *)c->t2, 0L, out);
+        else DCT_ROWS_ANY(0, (const double *)c->t2, 0L, out);
+        return 0;
+    }
     // T1 = g Q1f
     LAUNCHC(PC_GEMM, (k_gemm<false, 0>), g, dim3(256), ns, nf, nf, in, (long)G.pitch, G.plane, in_slot_stride, c->Q1f, (long)nf, 0L,
            c->t1, (long)G.pitch, G.plane, sp, c->st, gate);
@@ -1208,3 +1276,5 @@ extern "C" int vch2d_prof_end(vch2d_ctx *c, double *ms_out, int64_t *count_out, 
     }
     return (int)c->prof_cls.size();
 }
+
+extern "C" int vch2d_uses_fft(const vch2d_ctx *c) { return c ? (c->use_fft ? 1 : 0) : VCH_ERR_ARG; }

@@ -1,0 +1,223 @@
+// vch_fft.h — in-LDS FFT implementation of the fast-diagonalisation preconditioner for
+// power-of-two grids (N = 16 ... 2048 intervals per axis).
+//
+// The DCT-I (REDFT00)  E(x)_k = x_0 + (-1)^k x_N + 2 sum_{0<j<N} x_j cos(pi j k / N)  diagonalises the
+// mirrored-Neumann Laplacian and is its own inverse up to 2N, so
+//     (c0 + m (c1 + c2 m))^-1 v  =  E2( mult o E2(v) ) / (4 Nf Ns),     E2 = E along both axes.
+// E of a real sequence is the DFT of its even extension (length L = 2N), which is real; two real
+// rows a, b are therefore transformed by ONE complex FFT of a + i b: FFT = E(a) + i E(b).
+//
+// A workgroup of C/16 threads owns an LDS image of C complex doubles = NFFT = C/L transforms
+// (2 NFFT rows or columns of the plane); C = 1024 for L <= 1024, i.e. ONE wavefront and 16 KiB
+// of LDS per workgroup, so ~10 independent workgroups share a CU and hide each other's
+// global-memory and LDS latency (C = 2048 / 4096 for L = 2048 / 4096).  The FFT is a radix-4
+// Stockham autosort (plus one radix-2 pass when log2 L is odd), done in place: every thread
+// reads its 4 x 4 operands, barrier, writes them back transposed, barrier.  Twiddles come from a table of
+// exp(-2 pi i m / L) computed in long double on the host.
+//
+//   k_dct_rows : E along the fast (contiguous) axis for 2 NFFT rows; optional epilogue
+//                (weighted dot partial for the CG scalars)
+//   k_dct_cols : E along the slow axis for 2 NFFT columns, spectral multiplier, E again (the
+//                forward and the backward slow-axis transforms fused: one load, one store)
+#pragma once
+#include "vch_common.h"
+#include "vch_kernels2d.h"
+#include "vch_gemm.h"        // SpecArgs
+
+struct FftAxis {
+    int N, L, logL;          // intervals, FFT length 2N, log2 L
+    const double2 *tw;       // exp(-2 pi i m / L), m = 0..L-1
+};
+
+
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) {
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// In-place FFT of the NFFT = C/L sequences stored back to back in buf (C/16 threads).
+template <int C>
+__device__ __forceinline__ void fft_lds(double2 *buf, const FftAxis ax) {
+    constexpr int T = C / 16;
+    const int tid = threadIdx.x;
+    const int L = ax.L, logL = ax.logL;
+    int logNs = 0;
+    // radix-4 passes: C/4 butterflies = 4 per thread
+    const int logQ = logL - 2, Q = L >> 2;
+    for (; logNs + 2 <= logL; logNs += 2) {
+        const int Ns = 1 << logNs;
+        double2 v[4][4];
+        int wbase[4];
+        // the twiddles depend on k = j mod Ns only; for Ns <= T all four butterflies of a thread
+        // share them (j = tid + i T), so they are loaded once
+        const bool shared_tw = Ns <= T;
+        double2 w1 = make_double2(1.0, 0.0), w2 = w1, w3 = w1;
+        if (logNs > 0 && shared_tw) {
+            const int ti = (tid & (Ns - 1)) << (logL - logNs - 2);
+            w1 = ax.tw[ti];
+            w2 = ax.tw[2 * ti];
+            w3 = ax.tw[3 * ti];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + i * T;
+            const int f = idx >> logQ, j = idx & (Q - 1), k = j & (Ns - 1);
+            double2 *bp = buf + f * L;
+            double2 a = bp[j], b = bp[j + Q], c = bp[j + 2 * Q], d = bp[j + 3 * Q];
+            if (logNs > 0) {
+                if (!shared_tw) {
+                    const int ti = k << (logL - logNs - 2);
+                    w1 = ax.tw[ti];
+                    w2 = ax.tw[2 * ti];
+                    w3 = ax.tw[3 * ti];
+                }
+                b = cmul(b, w1);
+                c = cmul(c, w2);
+                d = cmul(d, w3);
+            }
+            double2 t0 = make_double2(a.x + c.x, a.y + c.y), t1 = make_double2(a.x - c.x, a.y - c.y);
+            double2 t2 = make_double2(b.x + d.x, b.y + d.y);
+            double2 t3 = make_double2(b.y - d.y, -(b.x - d.x));            // -i (b - d)
+            v[i][0] = make_double2(t0.x + t2.x, t0.y + t2.y);
+            v[i][1] = make_double2(t1.x + t3.x, t1.y + t3.y);
+            v[i][2] = make_double2(t0.x - t2.x, t0.y - t2.y);
+            v[i][3] = make_double2(t1.x - t3.x, t1.y - t3.y);
+            wbase[i] = f * L + ((j >> logNs) << (logNs + 2)) + k;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) buf[wbase[i] + r * Ns] = v[i][r];
+        __syncthreads();
+    }
+    if (logNs < logL) {          // one radix-2 pass: C/2 butterflies = 8 per thread
+        const int Ns = 1 << logNs, H = L >> 1, logH = logL - 1;
+        double2 v[8][2];
+        int wbase[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = tid + i * T;
+            const int f = idx >> logH, j = idx & (H - 1), k = j & (Ns - 1);
+            double2 *bp = buf + f * L;
+            double2 a = bp[j], b = cmul(bp[j + H], ax.tw[k << (logL - logNs - 1)]);
+            v[i][0] = make_double2(a.x + b.x, a.y + b.y);
+            v[i][1] = make_double2(a.x - b.x, a.y - b.y);
+            wbase[i] = f * L + ((j >> logNs) << (logNs + 1)) + k;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            buf[wbase[i]] = v[i][0];
+            buf[wbase[i] + Ns] = v[i][1];
+        }
+        __syncthreads();
+    }
+}
+
+// E along the fast axis.  EPI 0: out = scale * E(in);  EPI 3: same + per-workgroup partial of
+// sum W (D[slot] - dbar) (other ? other : out) * out  into sp.gpart[b * gridDim.x + blockIdx.x].
+template <int EPI, int C>
+__global__ __launch_bounds__(C / 16) void k_dct_rows(Geom G, FftAxis ax, const double *__restrict__ in,
+                                                  long in_slot_stride, double *__restrict__ out, double scale,
+                                                  SpecArgs sp, const TrajState *__restrict__ st, int gate) {
+    const int b = blockIdx.z;
+    if (gate && !st[b].lin_active) return;
+    __shared__ double2 buf[C];
+    constexpr int T = C / 16;
+    const int tid = threadIdx.x;
+    const int L = ax.L, N = ax.N, nfft = C >> ax.logL;
+    const int row0 = blockIdx.x * 2 * nfft;
+    const double *ib = in + b * G.plane + (in_slot_stride ? st[b].slot * in_slot_stride : 0);
+    const int n1 = N + 1;
+    const float inv_n1 = 1.0f / (float)n1;       // idx < 2^14: the float quotient is exact enough
+    for (int idx = tid; idx < nfft * n1; idx += T) {
+        const int f = (int)(((float)idx + 0.5f) * inv_n1), j = idx - f * n1;
+        const int ra = row0 + 2 * f, rb = ra + 1;
+        double2 v = make_double2(ra < G.ns ? ib[(long)ra * G.pitch + j] : 0.0,
+                                 rb < G.ns ? ib[(long)rb * G.pitch + j] : 0.0);
+        buf[f * L + j] = v;
+        if (j > 0 && j < N) buf[f * L + L - j] = v;
+    }
+    __syncthreads();
+    fft_lds<C>(buf, ax);
+    double dot = 0.0, dbar = 0.0;
+    const double *Dp = nullptr, *Ob = nullptr;
+    if (EPI == 3) {
+        dbar = st[b].dbar;
+        Dp = sp.Dslot + st[b].slot * sp.d_slot_stride + b * G.plane;
+        Ob = sp.other ? sp.other + b * G.plane : nullptr;
+    }
+    double *ob = out + b * G.plane;
+    for (int idx = tid; idx < 2 * nfft * n1; idx += T) {
+        const int rr = (int)(((float)idx + 0.5f) * inv_n1), k = idx - rr * n1;
+        const int row = row0 + rr;
+        if (row < G.ns) {
+            const double2 c = buf[(rr >> 1) * L + k];
+            const double v = scale * ((rr & 1) ? c.y : c.x);
+            const long o = (long)row * G.pitch + k;
+            ob[o] = v;
+            if (EPI == 3) dot += wdev(row, k, G) * (Dp[o] - dbar) * ((Ob ? Ob[o] : v) * v);
+        }
+    }
+    if (EPI == 3) {
+        dot = wave_sum(dot);
+        __syncthreads();
+        double *sred = reinterpret_cast<double *>(buf);
+        if ((tid & 63) == 0) sred[tid >> 6] = dot;
+        __syncthreads();
+        if (tid == 0) {
+            double tot = 0.0;
+            for (int w = 0; w < T / 64; ++w) tot += sred[w];
+            sp.gpart[(long)b * gridDim.x + blockIdx.x] = tot;
+        }
+    }
+}
+
+// E along the slow axis, spectral multiplier 1/(c0 + m (c1 + c2 m)) (m = ms[k] + mf[col]), E again.
+template <int C>
+__global__ __launch_bounds__(C / 16) void k_dct_cols(Geom G, FftAxis ax, const double *__restrict__ in,
+                                                  double *__restrict__ out, double scale, SpecArgs sp,
+                                                  const TrajState *__restrict__ st, int gate) {
+    const int b = blockIdx.z;
+    if (gate && !st[b].lin_active) return;
+    __shared__ double2 buf[C];
+    constexpr int T = C / 16;
+    const int tid = threadIdx.x;
+    const int L = ax.L, N = ax.N, nfft = C >> ax.logL, ncol = 2 * nfft;
+    const int col0 = blockIdx.x * ncol;
+    const double *ib = in + b * G.plane;
+    double *sb = reinterpret_cast<double *>(buf);
+    const int n1 = N + 1;
+    int lc = 0;                                   // log2(ncol)
+    while ((1 << lc) < ncol) ++lc;
+    for (int idx = tid; idx < n1 * ncol; idx += T) {
+        const int r = idx >> lc, cc = idx & (ncol - 1);
+        const int col = col0 + cc;
+        const double v = col < G.nf ? ib[(long)r * G.pitch + col] : 0.0;
+        const int f = cc >> 1, comp = cc & 1;
+        sb[2 * (f * L + r) + comp] = v;
+        if (r > 0 && r < N) sb[2 * (f * L + L - r) + comp] = v;
+    }
+    __syncthreads();
+    fft_lds<C>(buf, ax);
+    const double c1 = sp.c1a + sp.c1b * st[b].dbar;
+    for (int idx = tid; idx < nfft * L; idx += T) {
+        const int f = idx >> ax.logL, k = idx & (L - 1);
+        const int ks = k <= N ? k : L - k;
+        const int ca = col0 + 2 * f, cb = ca + 1;
+        const double msk = sp.ms[ks];
+        double2 v = buf[idx];
+        double ma = msk + sp.mf[ca < G.nf ? ca : G.nf - 1], mb = msk + sp.mf[cb < G.nf ? cb : G.nf - 1];
+        v.x *= scale / (sp.c0 + ma * (c1 + sp.c2 * ma));
+        v.y *= scale / (sp.c0 + mb * (c1 + sp.c2 * mb));
+        buf[idx] = v;
+    }
+    __syncthreads();
+    fft_lds<C>(buf, ax);
+    double *ob = out + b * G.plane;
+    for (int idx = tid; idx < n1 * ncol; idx += T) {
+        const int r = idx >> lc, cc = idx & (ncol - 1);
+        const int col = col0 + cc;
+        if (col < G.nf) ob[(long)r * G.pitch + col] = sb[2 * ((cc >> 1) * L + r) + (cc & 1)];
+    }
+}

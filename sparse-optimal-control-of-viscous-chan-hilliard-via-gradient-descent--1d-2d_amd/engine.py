@@ -64,6 +64,7 @@ class Engine2D:
         self.ctx = self.lib.vch2d_create(C.byref(self.p), self.B, self.max_steps, self.device)
         if not self.ctx:
             raise VchError("vch2d_create failed: " + _lib.last_error())
+        self.uses_fft = bool(self.lib.vch2d_uses_fft(self.ctx))
         self.x = np.linspace(0.0, float(Lx), self.Nx + 1)
         self.y = np.linspace(0.0, float(Ly), self.Ny + 1)
 
@@ -294,7 +295,7 @@ class Engine2D:
         return p.value
 
     # -- in-situ kernel timing -------------------------------------------------------------
-    PROF_CLASSES = ("schur_p", "gemm", "residual", "adj_q", "cg_update", "adj_rhs", "cost", "prox")
+    PROF_CLASSES = ("schur_p", "dct", "residual", "adj_q", "cg_update", "adj_rhs", "cost", "prox")
 
     def prof_begin(self, max_launches=200000):
         check(self.lib.vch2d_prof_begin(self.ctx, int(max_launches)))
