@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes per kernel (mean per dispatch over the
+non-skipped dispatches) and compare with the algorithmic bytes of DESIGN.md §4.
+
+Counter units/corrections as prescribed by MI355X_MICROARCH.md §HBM: the counters are in KiB
+(x1024); on gfx950 FETCH_SIZE under-reports wide coalesced streaming reads by exactly 2x for
+16 B/lane accesses and is uncalibrated for other widths, so the 8 B/lane read pattern of these
+kernels is calibrated in the same run on k_grad_prox, whose reads (u, r: 16 B/node, streamed once
+from histories far larger than the Infinity Cache) are known exactly."""
+import csv, glob, json, sys, collections
+
+out = sys.argv[1]
+N, B, M = 512, 8, 40
+nodes = (N + 1) * (N + 1) * B
+alg = {"k_schur_p<0>": (24, 16), "k_cg_update<0>": (40, 16), "k_residual<1>": (48, 40), "k_dct_rows<0, 1024>": (8, 8),
+       "k_dct_cols<1024>": (8, 8), "k_adj_q": (24, 8), "k_grad_prox": (16, 8), "k_cost": (24, 0)}
+res = {}
+for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+    files = glob.glob(f"{out}/{ctr}/*/*counter_collection.csv")
+    acc = collections.defaultdict(list)
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") != ctr:
+                continue
+            name = r["Kernel_Name"]
+            key = next((k for k in alg if name.startswith("void " + k) or name.startswith(k)), None)
+            if key:
+                acc[key].append(float(r["Counter_Value"]) * 1024.0)
+    for k, v in acc.items():
+        vmax = max(v)
+        live = [x for x in v if x > 0.25 * vmax]          # drop gated (skipped) dispatches
+        res.setdefault(k, {})[ctr] = dict(dispatches=len(v), live=len(live), mean_bytes=sum(live) / max(len(live), 1))
+summary = {}
+levels = M + 1
+cal = None
+if "k_grad_prox" in res and "FETCH_SIZE" in res["k_grad_prox"]:
+    known = 16.0 * nodes * levels
+    cal = res["k_grad_prox"]["FETCH_SIZE"]["mean_bytes"] / known
+for k, d in res.items():
+    rd, wr = alg[k]
+    mult = levels if k in ("k_grad_prox", "k_cost") else 1
+    f = d.get("FETCH_SIZE", {}).get("mean_bytes")
+    w = d.get("WRITE_SIZE", {}).get("mean_bytes")
+    summary[k] = dict(algorithmic_read=rd * nodes * mult, algorithmic_write=wr * nodes * mult,
+                      fetch_raw=f, write_raw=w,
+                      fetch_corrected=(f / cal if (f is not None and cal) else None),
+                      dispatches=d.get("FETCH_SIZE", d.get("WRITE_SIZE"))["dispatches"])
+print(json.dumps(dict(calibration_fetch_ratio_8B_per_lane=cal, kernels=summary), indent=1))

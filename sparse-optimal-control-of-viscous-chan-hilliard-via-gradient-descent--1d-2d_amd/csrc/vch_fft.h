@@ -30,6 +30,14 @@ struct FftAxis {
 };
 
 
+// XCD-aware bijective remap of a 1-D block index: workgroups are dealt round-robin over the 8
+// XCDs (blocks b and b+8 share an L2), so logically adjacent work items -- which here share
+// 128-byte lines -- are given to the SAME XCD in contiguous chunks.  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int bid, int n) {
+    const int q = n >> 3, r = n & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
     return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
@@ -184,7 +192,7 @@ __global__ __launch_bounds__(C / 16) void k_dct_cols(Geom G, FftAxis ax, const d
     constexpr int T = C / 16;
     const int tid = threadIdx.x;
     const int L = ax.L, N = ax.N, nfft = C >> ax.logL, ncol = 2 * nfft;
-    const int col0 = blockIdx.x * ncol;
+    const int col0 = xcd_remap(blockIdx.x, gridDim.x) * ncol;
     const double *ib = in + b * G.plane;
     double *sb = reinterpret_cast<double *>(buf);
     const int n1 = N + 1;
