@@ -202,6 +202,54 @@ int vch2d_pgd_cost_dev(vch2d_ctx *ctx, double **ptr_dev);
 int vch2d_prof_begin(vch2d_ctx *ctx, int max_launches);
 int vch2d_prof_end(vch2d_ctx *ctx, double *ms_out, int64_t *count_out, int ncls);
 
+/* ------------------------------------------------------------------ 1D ---- */
+
+typedef struct vch1d_params {          /* ForwardSolverConfig of the 1D code (K1:93-102) */
+    int32_t N;
+    double Lx;
+    double tau, gamma, c1, c2, kappa;
+} vch1d_params;
+
+typedef struct vch1d_ctx vch1d_ctx;
+
+vch1d_ctx *vch1d_create(const vch1d_params *p, int batch, int max_steps, int device);
+void vch1d_destroy(vch1d_ctx *ctx);
+
+/* out = L v (F1:64-80).  v,out [B][N+1]. */
+int vch1d_apply_laplacian(vch1d_ctx *ctx, const double *v, double *out);
+/* Replaces solve_phi_residual/solve_mu_residual (F1:93-109). */
+int vch1d_residuals(vch1d_ctx *ctx, const double *phi_new, const double *phi_old,
+                    const double *mu_new, const double *mu_old, const double *w_new,
+                    const double *w_old, double dt, double *Rphi_out, double *Rmu_out);
+/* Solve the 2(N+1) Newton system.  Replaces np.linalg.solve(J, -R) (F1:185): block
+ * (2x2) tridiagonal cyclic reduction in LDS, one workgroup per trajectory (N <= 4096). */
+int vch1d_jacobian_solve(vch1d_ctx *ctx, const double *phi_new, double dt, const double *rhs_phi,
+                         const double *rhs_mu, double *dphi, double *dmu);
+/* Solve A(phi_n) p = rhs with the frozen default parameters (B1:29-33, B1:116). */
+int vch1d_adjoint_solve(vch1d_ctx *ctx, const double *phi_n, double dt, const double *rhs,
+                        double *p_out);
+/* Replaces newton_raphson (F1:139-235). */
+int vch1d_newton_raphson(vch1d_ctx *ctx, const double *phi_old, const double *mu_old,
+                         const double *w_old, const double *w_new, double dt, double *phi_new,
+                         double *mu_new, double *hist, int hist_cap, int32_t *n_hist);
+/* Replaces run_main_simulation (F1:286-386): history has M+2 rows (duplicated t=0).
+ *   u [B][u_rows][N+1] or NULL; hold-last rule of F1:347-353 (u_rows < M errors like the
+ *   reference's IndexError).  phi_hist_out [B][M+2][N+1] or NULL. */
+int vch1d_forward(vch1d_ctx *ctx, const double *phi0, const double *u, int u_rows, const double *dt,
+                  int M, double *phi_hist_out, vch_stats *stats);
+/* Replaces run_backward (B1:48-126); rows = M+2, t_hist [rows]. */
+int vch1d_backward(vch1d_ctx *ctx, const double *phi_hist, int rows, const double *t_hist, double h,
+                   double b1, double b2, const double *phi_Q, const double *phi_T, double *p_out,
+                   double *q_out, double *r_out);
+/* Replaces calculate_cost (C1:26-84); J_out [B][5]. */
+int vch1d_cost(vch1d_ctx *ctx, const double *phi_hist, const double *u, const double *phi_Q,
+               const double *phi_T, int rows, const double *x, const double *t_hist,
+               const vch_opt_params *opt, double *J_out);
+/* Replaces calculate_gradient + perform_gradient_step + perform_proximal_and_projection
+ * (C1:86-112, G1:56-71). */
+int vch1d_grad_prox(vch1d_ctx *ctx, const double *u, const double *r, int rows, const double *alpha,
+                    const vch_opt_params *opt, double *u_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libvch_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 SOURCES = ["vch_hip.hip"]
-DEPS = ["vch_hip.hip", "vch_engine2d.hip", "vch_kernels2d.h", "vch_gemm.h", "vch_fft.h", "vch_common.h",
+DEPS = ["vch_hip.hip", "vch_engine2d.hip", "vch_kernels2d.h", "vch_gemm.h", "vch_fft.h", "vch_common.h", "vch_engine1d.hip", "vch_kernels1d.h",
         os.path.join(ROOT, "include", "vch.h")]
 
 
@@ -55,6 +55,11 @@ class Params2D(C.Structure):
     _fields_ = [("Nx", C.c_int32), ("Ny", C.c_int32), ("Lx", C.c_double), ("Ly", C.c_double),
                 ("tau", C.c_double), ("gamma", C.c_double), ("c1", C.c_double), ("c2", C.c_double),
                 ("kappa", C.c_double)]
+
+
+class Params1D(C.Structure):
+    _fields_ = [("N", C.c_int32), ("Lx", C.c_double), ("tau", C.c_double), ("gamma", C.c_double),
+                ("c1", C.c_double), ("c2", C.c_double), ("kappa", C.c_double)]
 
 
 class OptParams(C.Structure):
@@ -106,6 +111,17 @@ SIGNATURES = {
     "vch2d_pgd_iterate": (C.c_int, [_P, C.c_int, _D, _D, _I32, _D, _D]),
     "vch2d_pgd_get": (C.c_int, [_P, C.c_int, _D]),
     "vch2d_pgd_cost_dev": (C.c_int, [_P, C.POINTER(C.c_void_p)]),
+    "vch1d_create": (_P, [C.POINTER(Params1D), C.c_int, C.c_int, C.c_int]),
+    "vch1d_destroy": (None, [_P]),
+    "vch1d_apply_laplacian": (C.c_int, [_P, _D, _D]),
+    "vch1d_residuals": (C.c_int, [_P, _D, _D, _D, _D, _D, _D, C.c_double, _D, _D]),
+    "vch1d_jacobian_solve": (C.c_int, [_P, _D, C.c_double, _D, _D, _D, _D]),
+    "vch1d_adjoint_solve": (C.c_int, [_P, _D, C.c_double, _D, _D]),
+    "vch1d_newton_raphson": (C.c_int, [_P, _D, _D, _D, _D, C.c_double, _D, _D, _D, C.c_int, _I32]),
+    "vch1d_forward": (C.c_int, [_P, _D, _D, C.c_int, _D, C.c_int, _D, C.POINTER(Stats)]),
+    "vch1d_backward": (C.c_int, [_P, _D, C.c_int, _D, C.c_double, C.c_double, C.c_double, _D, _D, _D, _D, _D]),
+    "vch1d_cost": (C.c_int, [_P, _D, _D, _D, _D, C.c_int, _D, _D, C.POINTER(OptParams), _D]),
+    "vch1d_grad_prox": (C.c_int, [_P, _D, _D, C.c_int, _D, C.POINTER(OptParams), _D]),
     "vch2d_prof_begin": (C.c_int, [_P, C.c_int]),
     "vch2d_prof_end": (C.c_int, [_P, _D, C.POINTER(C.c_int64), C.c_int]),
 }

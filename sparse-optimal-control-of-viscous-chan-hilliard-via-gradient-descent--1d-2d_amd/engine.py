@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import OptParams, Params2D, Stats, VchError, check
+from ._lib import OptParams, Params1D, Params2D, Stats, VchError, check
 
 
 def _dp(a):
@@ -306,3 +306,141 @@ class Engine2D:
         cnt = np.zeros(n, dtype=np.int64)
         check(self.lib.vch2d_prof_end(self.ctx, _dp(ms), cnt.ctypes.data_as(C.POINTER(C.c_int64)), n))
         return {k: dict(ms=float(ms[i]), launches=int(cnt[i])) for i, k in enumerate(self.PROF_CLASSES)}
+
+
+class Engine1D:
+    """One GPU context for `batch` 1D trajectories on N+1 nodes (N <= 4096)."""
+
+    def __init__(self, N, Lx=1.0, tau=0.05, gamma=10.0, c1=0.75, c2=1.0, kappa=0.03 ** 2, batch=1,
+                 max_steps=128, device=0):
+        self.lib = _lib.load()
+        if self.lib.vch_device_count() <= 0:
+            raise VchError("no HIP device visible: the engine has no CPU path")
+        self.p = Params1D(int(N), float(Lx), float(tau), float(gamma), float(c1), float(c2), float(kappa))
+        self.B, self.max_steps, self.N, self.n = int(batch), int(max_steps), int(N), int(N) + 1
+        self.ctx = self.lib.vch1d_create(C.byref(self.p), self.B, self.max_steps, int(device))
+        if not self.ctx:
+            raise ValueError("vch1d_create failed: " + _lib.last_error())
+        self.x = np.linspace(0, float(Lx), self.n)
+
+    @classmethod
+    def from_config(cls, cfg, **kw):
+        return cls(cfg.N, cfg.Lx, cfg.tau, cfg.gamma, cfg.c1, cfg.c2, cfg.kappa, **kw)
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.vch1d_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _fld(self, a, name="field"):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        if a.shape == (self.n,) and self.B == 1:
+            a = a.reshape(1, self.n)
+        if a.shape != (self.B, self.n):
+            raise ValueError(f"{name} must have shape ({self.n},) [batch {self.B}], got {a.shape}")
+        return a
+
+    def _hist(self, a, rows=0, name="history"):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        if a.ndim == 2 and self.B == 1:
+            a = a.reshape((1,) + a.shape)
+        if a.ndim != 3 or a.shape[0] != self.B or a.shape[2] != self.n or (rows and a.shape[1] != rows):
+            raise ValueError(f"{name} must have shape (rows, {self.n}), got {a.shape}")
+        return a
+
+    def _sq(self, a):
+        return a[0] if self.B == 1 else a
+
+    def apply_laplacian(self, v):
+        v = self._fld(v)
+        out = np.empty_like(v)
+        check(self.lib.vch1d_apply_laplacian(self.ctx, _dp(v), _dp(out)))
+        return self._sq(out)
+
+    def residuals(self, phi_new, phi_old, mu_new, mu_old, w_new, w_old, dt):
+        a = [self._fld(v) for v in (phi_new, phi_old, mu_new, mu_old, w_new, w_old)]
+        Rp, Rm = np.empty_like(a[0]), np.empty_like(a[0])
+        check(self.lib.vch1d_residuals(self.ctx, *[_dp(v) for v in a], float(dt), _dp(Rp), _dp(Rm)))
+        return self._sq(Rp), self._sq(Rm)
+
+    def jacobian_solve(self, phi_new, dt, rhs_phi, rhs_mu):
+        a = [self._fld(v) for v in (phi_new, rhs_phi, rhs_mu)]
+        o1, o2 = np.empty_like(a[0]), np.empty_like(a[0])
+        check(self.lib.vch1d_jacobian_solve(self.ctx, _dp(a[0]), float(dt), _dp(a[1]), _dp(a[2]), _dp(o1), _dp(o2)))
+        return self._sq(o1), self._sq(o2)
+
+    def adjoint_solve(self, phi_n, dt, rhs):
+        phi_n = None if phi_n is None else self._fld(phi_n)
+        rhs = self._fld(rhs)
+        out = np.empty_like(rhs)
+        check(self.lib.vch1d_adjoint_solve(self.ctx, _dp(phi_n), float(dt), _dp(rhs), _dp(out)))
+        return self._sq(out)
+
+    def newton_raphson(self, phi_old, mu_old, w_old, w_new, dt, hist_cap=64):
+        a = [self._fld(v) for v in (phi_old, mu_old, w_old, w_new)]
+        pn, mn = np.empty_like(a[0]), np.empty_like(a[0])
+        hist = np.zeros((self.B, hist_cap))
+        nh = np.zeros(self.B, dtype=np.int32)
+        check(self.lib.vch1d_newton_raphson(self.ctx, *[_dp(v) for v in a], float(dt), _dp(pn), _dp(mn), _dp(hist),
+                                            int(hist_cap), nh.ctypes.data_as(_lib._I32)))
+        hists = [hist[b, :nh[b]].copy() for b in range(self.B)]
+        return self._sq(pn), self._sq(mn), (hists[0] if self.B == 1 else hists)
+
+    def forward(self, phi0, dt, u=None, store=True):
+        """Returns (phi_hist with M+2 rows or None, stats)."""
+        phi0 = self._fld(phi0, "phi0")
+        dt = np.ascontiguousarray(dt, dtype=np.float64)
+        M = int(dt.size)
+        rows = 0
+        if u is not None:
+            u = self._hist(u, 0, "control_input")
+            rows = int(u.shape[1])
+            if rows < M:          # the reference indexes control_input[step] for every step (F1:347-353)
+                raise IndexError(f"index {rows} is out of bounds for axis 0 with size {rows}")
+            if rows > M + 2:
+                u = np.ascontiguousarray(u[:, :M + 2])
+                rows = M + 2
+        out = np.empty((self.B, M + 2, self.n)) if store else None
+        st = Stats()
+        check(self.lib.vch1d_forward(self.ctx, _dp(phi0), _dp(u), rows, _dp(dt), M, _dp(out), C.byref(st)))
+        return (self._sq(out) if store else None), st.as_dict()
+
+    def backward(self, phi_hist, t_hist, b1, b2, phi_Q=None, phi_T=None, h=None):
+        t_hist = np.ascontiguousarray(t_hist, dtype=np.float64)
+        rows = int(t_hist.size)
+        ph = None if phi_hist is None else self._hist(phi_hist, rows, "phi_hist")
+        pq = None if phi_Q is None else self._hist(phi_Q, rows, "phi_Q")
+        pt = None if phi_T is None else self._fld(phi_T, "phi_T_target")
+        p, q, r = (np.empty((self.B, rows, self.n)) for _ in range(3))
+        h = float(self.x[1] - self.x[0]) if h is None else float(h)
+        check(self.lib.vch1d_backward(self.ctx, _dp(ph), rows, _dp(t_hist), h, float(b1), float(b2), _dp(pq), _dp(pt),
+                                      _dp(p), _dp(q), _dp(r)))
+        return self._sq(p), self._sq(q), self._sq(r)
+
+    def cost(self, phi_hist, u, phi_Q, phi_T, x, t_hist, opt):
+        t_hist = np.ascontiguousarray(t_hist, dtype=np.float64)
+        rows = int(t_hist.size)
+        ph = self._hist(phi_hist, rows, "phi_hist")
+        uu = None if u is None else self._hist(u, rows, "u")
+        pq = None if phi_Q is None else self._hist(phi_Q, rows, "phi_Q_target")
+        pt = None if phi_T is None else self._fld(phi_T, "phi_T_target")
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        J = np.empty((self.B, 5))
+        o = opt if isinstance(opt, OptParams) else make_opt(opt)
+        check(self.lib.vch1d_cost(self.ctx, _dp(ph), _dp(uu), _dp(pq), _dp(pt), rows, _dp(x), _dp(t_hist), C.byref(o), _dp(J)))
+        return J[0] if self.B == 1 else J
+
+    def grad_prox(self, u, r, alpha, opt):
+        u = self._hist(u, 0, "u")
+        r = self._hist(r, u.shape[1], "r")
+        al = np.ascontiguousarray(np.broadcast_to(np.asarray(alpha, dtype=np.float64), (self.B,)))
+        out = np.empty_like(u)
+        o = opt if isinstance(opt, OptParams) else make_opt(opt)
+        check(self.lib.vch1d_grad_prox(self.ctx, _dp(u), _dp(r), int(u.shape[1]), _dp(al), C.byref(o), _dp(out)))
+        return self._sq(out)
