@@ -113,7 +113,9 @@ def main():
     t_hist, dts = vch_amd.time_grid(T, dt)
     M = len(dts)
     eng = vch_amd.Engine2D(Nx=N, Ny=N, batch=B, max_steps=M, device=local)
-    seeds = [42 + rank * B + i for i in range(B)]
+    par = vch_amd.parallel
+    dev = f"cuda:{local}" if dist is not None else "cpu"
+    seeds = par.shard_seeds(rank, max(world, 1), B)
     phi0 = np.stack([O2.init_phi_random(N, N, 1e-2, amp=0.1, seed=s) for s in seeds])
     xs = np.linspace(0.0, 1.0, N + 1)
     phi_T = 0.7 * np.sin(2 * np.pi * xs)[:, None] * np.cos(np.pi * xs)[None, :]       # G2:199
@@ -122,42 +124,29 @@ def main():
     J0 = eng.pgd_init(phi0, np.broadcast_to(phi_T, phi0.shape).copy(), t_hist, opt, ramp=True, T=T)
     t_init = time.perf_counter() - t_init
 
-    def allreduce_cost(J):
-        if dist is None:
-            return J.sum(axis=0)
-        import torch
-        t = torch.from_numpy(np.ascontiguousarray(J.sum(axis=0))).cuda()
-        dist.all_reduce(t)                      # the single RCCL collective of an iteration
-        return t.cpu().numpy()
-
-    def sync():
-        if dist is not None:
-            import torch
-            dist.barrier()
-            torch.cuda.synchronize()
+    def step_costs(r):
+        """[B][5] costs of this rank after an iteration: total from the engine, parts not needed"""
+        J = np.zeros((B, 5))
+        J[:, 4] = r["cost"][:, 0]
+        return J
 
     costs = []
     for _ in range(a.warmup):
         r = eng.pgd_iterate(1)
-        allreduce_cost(r["cost"])
-    sync()
+        par.allreduce_cost(step_costs(r), dist, dev)
+    par.barrier(dist, dev)
     t0 = time.perf_counter()
     buckets = {}
     attempts = 0
     for _ in range(a.steps):
         r = eng.pgd_iterate(1)                  # synchronous: returns when the device is done
-        Jsum = allreduce_cost(r["cost"])
-        costs.append(float(np.asarray(Jsum).ravel()[0]))
+        Jsum = par.allreduce_cost(step_costs(r), dist, dev)      # the single RCCL collective of an iteration
+        costs.append(float(Jsum[4]))
         attempts += int(r["attempts"].sum())
         for k, v in r["seconds"].items():
             buckets[k] = buckets.get(k, 0.0) + float(v)
-    sync()
-    el = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([el], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+    par.barrier(dist, dev)
+    el = par.max_over_ranks(time.perf_counter() - t0, dist, dev)
     total_traj = B * max(world, 1)
     value = a.steps * total_traj / el
 

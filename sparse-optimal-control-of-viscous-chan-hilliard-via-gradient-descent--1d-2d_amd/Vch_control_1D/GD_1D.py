@@ -1,0 +1,128 @@
+"""Host-side mirror of the reusable parts of src/1D/Vch_control_1D/GD_1D.py: the prox, the
+line search, the sparsity (KKT) check, target construction, and the optimisation loop of the
+`__main__` block (G1:333-477) as a callable.  Prompts and plots are out of scope."""
+from __future__ import annotations
+
+import contextlib
+import io
+
+import numpy as np
+
+from ..engine import make_opt
+from .Forward_solver import run_main_simulation
+from .backward_solver import run_backward
+from .cost_and_function import calculate_cost, calculate_gradient, perform_gradient_step
+from .config import ForwardSolverConfig, OptimizationConfig
+from ._ctx import engine_for
+
+INTERACTIVE = False
+DEFAULT_TARGET_CHOICE = 1
+DEFAULT_TRACKING_CHOICE = 1
+
+
+def perform_proximal_and_projection(u_temp, alpha, kappa, u_min, u_max):
+    """Soft threshold alpha*kappa then box projection (G1:56-71), on the GPU: the engine's fused
+    kernel is called with r = 0, b3 = 0 and step 0 on the already stepped control."""
+    u_temp = np.asarray(u_temp, dtype=np.float64)
+    shp = u_temp.shape
+    u2 = u_temp.reshape(-1, shp[-1]) if u_temp.ndim > 1 else u_temp.reshape(1, -1)
+    eng = engine_for(u2.shape[1] - 1, max_steps=max(u2.shape[0], 1))
+    # prox(v) with v = u - alpha*(r + b3 u): choose r = 0, b3 = 0 so that v = u
+    o = make_opt(b3=0.0, kappa_sparsity=float(kappa), u_min=float(u_min), u_max=float(u_max))
+    out = eng.grad_prox(u2, np.zeros_like(u2), float(alpha), o)
+    return np.asarray(out).reshape(shp)
+
+
+def perform_backtracking_line_search(u_k, cost_k, grad_smooth, phi_Q_target, phi_T_target, x, t_hist, b1, b2, b3,
+                                     kappa, u_min, u_max, fwd_config, alpha_init=10.0, beta=0.8, max_ls_iter=5):
+    """G1:73-113."""
+    alpha, n_trials = alpha_init, 0
+    u_next = phi_next = None
+    cost_next = cost_k
+    for _ in range(max_ls_iter):
+        n_trials += 1
+        u_next = perform_proximal_and_projection(perform_gradient_step(u_k, grad_smooth, alpha), alpha, kappa, u_min, u_max)
+        phi_next, _, _ = run_main_simulation(fwd_config, store_history=True, control_input=u_next, verbose=False)
+        with contextlib.redirect_stdout(io.StringIO()):
+            cost_next = calculate_cost(phi_next, u_next, phi_Q_target, phi_T_target, x, t_hist, b1, b2, b3, kappa, verbose=False)
+        if cost_next < cost_k:
+            return alpha, u_next, cost_next, phi_next, 0.0, 0.0, n_trials
+        alpha *= beta
+    return alpha, u_next, cost_next, phi_next, 0.0, 0.0, n_trials
+
+
+def verify_sparsity_condition(u_optimal, r_optimal, kappa, tol=1e-6, verbose=True):
+    """u* = 0  <=>  |r*| <= kappa match statistics (G1:115-147).  Returns (sparsity %, |r|<=kappa %,
+    match %)."""
+    is_u_zero = np.abs(u_optimal) < tol
+    is_r_small = np.abs(r_optimal) <= kappa
+    total = u_optimal.size
+    res = (100.0 * np.sum(is_u_zero) / total, 100.0 * np.sum(is_r_small) / total,
+           100.0 * np.sum(is_u_zero == is_r_small) / total)
+    if verbose:
+        print(f"Sparsity of final control (u* ~ 0): {res[0]:.2f}%")
+        print(f"Region where |r*| <= kappa:          {res[1]:.2f}%")
+        print(f"Percentage of points where the conditions match: {res[2]:.2f}%")
+    return res
+
+
+def build_targets_1d(x, t_hist, phi_initial, Lx, T, interactive=False, choice_t=DEFAULT_TARGET_CHOICE,
+                     choice_q=DEFAULT_TRACKING_CHOICE, A_T=0.7, k_tan=0.45):
+    """G1:151-254 (non-interactive)."""
+    if choice_t == 1:
+        phi_T = A_T * np.sin(2.0 * np.pi * x / Lx)
+    elif choice_t == 2:
+        phi_T = A_T * np.cos(2.0 * np.pi * x / Lx)
+    else:
+        tr = np.tan(2.0 * np.pi * k_tan * (x / Lx - 0.5))
+        sc = np.max(np.abs(tr))
+        phi_T = A_T * (tr / (sc if sc > 1e-12 else 1.0))
+    if choice_q == 1:
+        tp = (t_hist / (t_hist[-1] if t_hist[-1] > 0 else 1.0))[:, np.newaxis]
+        phi_Q = (1.0 - tp) * phi_initial + tp * phi_T
+    else:
+        phi_Q = np.zeros((len(t_hist), len(x)))
+    return phi_T, phi_Q
+
+
+def run_optimization(fwd_config: ForwardSolverConfig, opt_config: OptimizationConfig, n_iter=None, choice_t=1,
+                     choice_q=1):
+    """The loop of G1:333-477 -> dict(costs, alphas, trials, u, phi, r, converged)."""
+    O = opt_config
+    quiet = contextlib.redirect_stdout(io.StringIO())
+    phi_k, x, t_hist = run_main_simulation(fwd_config, store_history=True, verbose=False)
+    u_k = np.zeros_like(phi_k)
+    phi_T, phi_Q = build_targets_1d(x, t_hist, phi_k[0].copy(), float(fwd_config.Lx), float(fwd_config.T),
+                                    choice_t=choice_t, choice_q=choice_q)
+    with quiet:
+        cost_k = calculate_cost(phi_k, u_k, phi_Q, phi_T, x, t_hist, O.b1, O.b2, O.b3, O.kappa_sparsity)
+    costs, alphas, trials = [cost_k], [], []
+    alpha_prev, plateau, converged = O.alpha_max, 0, False
+    r_k = None
+    for k in range(O.max_iter if n_iter is None else n_iter):
+        _, _, r_k = run_backward(phi_k, x, t_hist, O.b1, O.b2, phi_Q, phi_T)
+        g = calculate_gradient(r_k, u_k, O.b3)
+        u_o = perform_proximal_and_projection(perform_gradient_step(u_k, g, alpha_prev), alpha_prev,
+                                              O.kappa_sparsity, O.u_min, O.u_max)
+        phi_o, _, _ = run_main_simulation(fwd_config, store_history=True, control_input=u_o, verbose=False)
+        with contextlib.redirect_stdout(io.StringIO()):
+            c_o = calculate_cost(phi_o, u_o, phi_Q, phi_T, x, t_hist, O.b1, O.b2, O.b3, O.kappa_sparsity, verbose=False)
+        if c_o < cost_k:
+            a_k, u_n, c_n, phi_n, nt = alpha_prev, u_o, c_o, phi_o, 1
+        else:
+            a_k, u_n, c_n, phi_n, _, _, nt = perform_backtracking_line_search(
+                u_k, cost_k, g, phi_Q, phi_T, x, t_hist, O.b1, O.b2, O.b3, O.kappa_sparsity, O.u_min, O.u_max,
+                fwd_config, alpha_init=alpha_prev)
+        costs.append(c_n); alphas.append(a_k); trials.append(nt)
+        plateau = plateau + 1 if (k > 0 and abs(costs[-1] - costs[-2]) < 1e-7) else 0
+        if plateau >= 10:
+            alpha_prev, plateau = min(O.alpha_max, a_k * 2.0), 0
+        else:
+            alpha_prev = min(O.alpha_max, a_k * 1.2)
+        change = np.linalg.norm(u_n - u_k) / (np.linalg.norm(u_k) + 1e-9)
+        if change < 1e-5 and k > 10:
+            u_k, converged = u_n.copy(), True
+            break
+        u_k, cost_k, phi_k = u_n.copy(), c_n, phi_n
+    return dict(costs=costs, alphas=alphas, trials=trials, u=u_k, phi=phi_k, r=r_k, converged=converged,
+                phi_T=phi_T, phi_Q=phi_Q, x=x, t_hist=t_hist)

@@ -6,6 +6,7 @@ The directory name is not a valid Python identifier; import it through the `vch_
 shim at the repository root (`import vch_amd`) or with importlib.
 """
 from ._lib import VchError, build, load, LIB_PATH          # noqa: F401
+from . import parallel                                         # noqa: F401
 from .engine import Engine1D, Engine2D, make_opt, time_grid  # noqa: F401
 
-__all__ = ["VchError", "build", "load", "LIB_PATH", "Engine1D", "Engine2D", "make_opt", "time_grid"]
+__all__ = ["parallel", "VchError", "build", "load", "LIB_PATH", "Engine1D", "Engine2D", "make_opt", "time_grid"]

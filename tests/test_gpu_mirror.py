@@ -1,0 +1,108 @@
+"""The reference-named Python modules (the drop-in function seam) on the GPU: the same calls the
+reference's drivers and tests make, checked against the goldens."""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+
+from conftest import golden, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def V():
+    import vch_amd
+    vch_amd.build()
+    return vch_amd
+
+
+def test_2d_function_seam(V):
+    F2 = V.module("Vch_control_2D.Forward2_solver")
+    B2 = V.module("Vch_control_2D.backward2_solver")
+    C2 = V.module("Vch_control_2D.cost2_and_function")
+    K2 = V.module("Vch_control_2D.config")
+    g = golden("g2d_forward_16.npz")
+    cfg = K2.ForwardSolverConfig(Nx=16, Ny=16, T=float(g["T"]), dt_initial=float(g["dt"]))
+    opt = K2.OptimizationConfig()
+    phi, (x, y), t = F2.run_main_simulation(cfg, store_history=True, control_input=None, verbose=False)
+    assert np.array_equal(t, g["t_hist"]) and np.array_equal(x, g["x"])
+    assert relerr(phi, g["phi_nat"]) < 1e-9
+    phi_u, _, _ = F2.run_main_simulation(cfg, store_history=True, control_input=g["u"], verbose=False)
+    assert relerr(phi_u, g["phi_u"]) < 1e-9
+    with pytest.raises(ValueError):
+        F2.run_main_simulation(cfg, store_history=True, control_input=np.zeros((3, 5, 5)), verbose=False)
+    p, q, r = B2.run_backward(g["phi_u"], x, y, t, cfg, opt.b1, opt.b2, g["phi_Q_11"], g["phi_T_11"])
+    assert relerr(r, g["r_11"]) < 1e-9 and relerr(p, g["p_11"]) < 1e-9
+    with pytest.raises(AssertionError):
+        B2.run_backward(g["phi_u"][0], x, y, t, cfg, 1.0, 1.0)
+    with contextlib.redirect_stdout(io.StringIO()) as out:
+        J = C2.calculate_cost(g["phi_u"], g["u"], g["phi_Q_11"], g["phi_T_11"], x, y, t, opt)
+    assert abs(J / float(g["J_11"]) - 1) < 1e-12 and "Tracking Cost (J1)" in out.getvalue()
+    gr = C2.calculate_gradient(g["r_11"], g["u"], opt)
+    assert np.array_equal(gr, g["grad"])
+    assert relerr(C2.proximal_step(g["u"], gr, 0.5, opt), g["prox_a0.5"]) < 1e-14
+    # operator handles
+    go = golden("g2d_ops_16.npz")
+    L = F2.laplacian_matrix_neumann(16, 16, 1 / 16, 1 / 16)
+    assert relerr(F2.apply_laplacian(L, go["v"], 16, 16), go["Lv"]) < 1e-12
+    assert relerr((L @ go["v"].ravel()).reshape(17, 17), go["Lv"]) < 1e-12
+    with pytest.raises(ValueError):
+        F2.apply_laplacian(L, go["v"][:5], 16, 16)
+    J = F2.assemble_jacobian(go["phi_new"], float(go["dt"]), 0.05, 0.75, 1e-4, L, 1e-2)
+    assert relerr(J @ go["dvec"], go["Jd"]) < 1e-12
+    assert relerr(J.solve(go["rhs"]), go["Jsol"]) < 1e-9
+    gn = golden("g2d_newton_32.npz")
+    L32 = F2.laplacian_matrix_neumann(32, 32, 1 / 32, 1 / 32)
+    pn, mn, hist = F2.newton_raphson(gn["phi0"], gn["mu_init"], gn["w0"], gn["w1"], 1e-2, 0.05, 0.75, 1.0, 1e-4, 1e-2,
+                                     L32, 32, 32, 1 / 32, 1 / 32, return_residual_history=True)
+    assert len(hist) == len(gn["hist_dt1e-2"]) and relerr(pn, gn["phi_new_dt1e-2"]) < 1e-9
+    assert np.array_equal(F2.init_phi_random(16, 16, 1e-2, amp=0.1, seed=43), golden("g2d_init_phi.npz")["N16_s43_a0.1"])
+
+
+def test_2d_driver_loop(V):
+    G2 = V.module("Vch_control_2D.GD2_configured")
+    K2 = V.module("Vch_control_2D.config")
+    g = golden("g2d_pgd_16_bt.npz")
+    cfg = K2.ForwardSolverConfig(Nx=16, Ny=16, T=float(g["T"]), dt_initial=float(g["dt"]))
+    opt = K2.OptimizationConfig(alpha_max=float(g["alpha_max"]))
+    res = G2.run_optimization(cfg, opt, n_iter=int(g["n_iter"]))
+    assert np.allclose(res["costs"][0], g["costs"], rtol=1e-8)
+    assert list(res["attempts"][0]) == list(g["attempts"])
+    assert relerr(res["u"], g["u_final"]) < 1e-8
+    phi_T, phi_Q = G2.build_targets(res["x"], res["y"], res["t_hist"], res["phi"][0], 1.0, 1.0, cfg.T, choice_t=1, choice_q=1)
+    assert relerr(phi_T, g["phi_T"]) < 1e-15
+
+
+def test_1d_function_seam_and_driver(V):
+    F1 = V.module("Vch_control_1D.Forward_solver")
+    B1 = V.module("Vch_control_1D.backward_solver")
+    C1 = V.module("Vch_control_1D.cost_and_function")
+    G1 = V.module("Vch_control_1D.GD_1D")
+    K1 = V.module("Vch_control_1D.config")
+    g = golden("g1d_forward_64.npz")
+    cfg = K1.ForwardSolverConfig(N=64, T=float(g["T"]), dt_initial=float(g["dt"]))
+    opt = K1.OptimizationConfig()
+    phi, x, t = F1.run_main_simulation(cfg, store_history=True, verbose=False)
+    assert np.array_equal(t, g["t_hist"]) and relerr(phi, g["phi_nat"]) < 1e-9
+    p, q, r = B1.run_backward(g["phi_u"], x, t, opt.b1, opt.b2, g["phi_Q_1"], g["phi_T_1"])
+    assert relerr(r, g["r"]) < 1e-9
+    with contextlib.redirect_stdout(io.StringIO()):
+        J = C1.calculate_cost(g["phi_u"], g["u"], g["phi_Q_1"], g["phi_T_1"], x, t, opt.b1, opt.b2, opt.b3, opt.kappa_sparsity)
+    assert abs(J / float(g["J"]) - 1) < 1e-12
+    ut = C1.perform_gradient_step(g["u"], C1.calculate_gradient(g["r"], g["u"], opt.b3), 7.0)
+    assert relerr(G1.perform_proximal_and_projection(ut, 7.0, opt.kappa_sparsity, opt.u_min, opt.u_max), g["prox"]) < 1e-14
+    for ct in (1, 2, 3):
+        phi_T, phi_Q = G1.build_targets_1d(x, t, g["phi_nat"][0], 1.0, cfg.T, choice_t=ct, choice_q=1)
+        assert relerr(phi_T, g[f"phi_T_{ct}"]) < 1e-15 and relerr(phi_Q, g[f"phi_Q_{ct}"]) < 1e-15
+    for tag in ("32", "32_bt"):
+        gp = golden(f"g1d_pgd_{tag}.npz")
+        cfgp = K1.ForwardSolverConfig(N=int(gp["N"]), T=float(gp["T"]), dt_initial=float(gp["dt"]))
+        optp = K1.OptimizationConfig(alpha_max=float(gp["alpha_max"]))
+        res = G1.run_optimization(cfgp, optp, n_iter=int(gp["n_iter"]))
+        assert np.allclose(res["costs"], gp["costs"], rtol=1e-9)
+        assert np.allclose(res["alphas"], gp["alphas"], rtol=1e-14) and list(res["trials"]) == list(gp["trials"])
+        assert relerr(res["u"], gp["u_final"]) < 1e-8
+    st = G1.verify_sparsity_condition(res["u"], res["r"], optp.kappa_sparsity, verbose=False)
+    assert 0.0 <= st[2] <= 100.0
