@@ -13,7 +13,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-LIB_PATH = os.path.join(HERE, "libvch_hip.so")
+LIB_PATH = os.environ.get("VCH_LIB") or os.path.join(HERE, "libvch_hip.so")     # VCH_LIB: A/B builds
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 SOURCES = ["vch_hip.hip"]
 DEPS = ["vch_hip.hip", "vch_engine2d.hip", "vch_kernels2d.h", "vch_gemm.h", "vch_fft.h", "vch_common.h", "vch_engine1d.hip", "vch_kernels1d.h",
@@ -35,20 +35,22 @@ def _stale():
     return False
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, defines=(), out=None) -> str:
     """Compile the HIP engine for gfx950 into the package directory (hipcc cross-compiles
-    without a GPU).  Returns the path of the shared library."""
-    if not force and not _stale():
+    without a GPU).  Returns the path of the shared library.  `defines`/`out`: tuning builds."""
+    if out is None and os.environ.get("VCH_LIB"):
+        return LIB_PATH                      # an explicitly selected prebuilt variant
+    if out is None and not force and not _stale():
         return LIB_PATH
     cmd = [HIPCC, "-O3", "--offload-arch=gfx950", "-shared", "-fPIC", "-std=c++17",
            "-Wno-unused-value", "-Wno-unused-result", "-I", CSRC,
-           "-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-o", out or LIB_PATH] + [f"-D{d}" for d in defines] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise VchError("hipcc failed:\n" + r.stdout + r.stderr)
-    return LIB_PATH
+    return out or LIB_PATH
 
 
 class Params2D(C.Structure):

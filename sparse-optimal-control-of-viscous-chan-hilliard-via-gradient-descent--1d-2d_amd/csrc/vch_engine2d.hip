@@ -358,13 +358,13 @@ static int precond(vch2d_ctx *c, const double *in, long in_slot_stride, double *
 #define DCT_ROWS(EPI_, C_, in_, iss_, out_)                                                                     \
     do {                                                                                                        \
         const int rpw = 2 * (C_ >> c->fax.logL);                                                                \
-        LAUNCHC(PC_GEMM, (k_dct_rows<EPI_, C_>), dim3((ns + rpw - 1) / rpw, 1, c->B), dim3(C_ / 16), G, c->fax, \
+        LAUNCHC(PC_GEMM, (k_dct_rows<EPI_, C_>), dim3((ns + rpw - 1) / rpw, 1, c->B), dim3(FftThreads<C_>::T), G, c->fax, \
                 in_, iss_, out_, 1.0, sp, c->st, gate);                                                         \
     } while (0)
 #define DCT_COLS(C_)                                                                                            \
     do {                                                                                                        \
         const int cpw = 2 * (C_ >> c->sax.logL);                                                                \
-        LAUNCHC(PC_GEMM, (k_dct_cols<C_>), dim3((nf + cpw - 1) / cpw, 1, c->B), dim3(C_ / 16), G, c->sax,       \
+        LAUNCHC(PC_GEMM, (k_dct_cols<C_>), dim3((nf + cpw - 1) / cpw, 1, c->B), dim3(FftThreads<C_>::T), G, c->sax,       \
                 (const double *)c->t1, c->t2, scale, sp, c->st, gate);                                          \
     } while (0)
 #define DCT_ROWS_ANY(EPI_, in_, iss_, out_)                                  \

@@ -7,10 +7,13 @@
 // E of a real sequence is the DFT of its even extension (length L = 2N), which is real; two real
 // rows a, b are therefore transformed by ONE complex FFT of a + i b: FFT = E(a) + i E(b).
 //
-// A workgroup of C/16 threads owns an LDS image of C complex doubles = NFFT = C/L transforms
-// (2 NFFT rows or columns of the plane); C = 1024 for L <= 1024, i.e. ONE wavefront and 16 KiB
-// of LDS per workgroup, so ~10 independent workgroups share a CU and hide each other's
-// global-memory and LDS latency (C = 2048 / 4096 for L = 2048 / 4096).  The FFT is a radix-4
+// A workgroup of C/8 threads owns an LDS image of C complex doubles = NFFT = C/L transforms
+// (2 NFFT rows or columns of the plane); C = 1024 for L <= 1024, i.e. TWO wavefronts and 16 KiB
+// of LDS per workgroup, so ~10 independent workgroups (20 waves) share a CU and hide each other's
+// global-memory and LDS latency (C = 2048 / 4096 for L = 2048 / 4096).  Measured on MI355X at
+// 512^2 x 8 (profiles/r01_c_fft_variants.txt): the kernels are latency-bound, not bank-conflict
+// bound -- 2 waves per transform beat 1 and 4, padding the image (fewer resident workgroups) and
+// writing the last pass straight to global memory (narrower stores) both lose.  The FFT is a radix-4
 // Stockham autosort (plus one radix-2 pass when log2 L is odd), done in place: every thread
 // reads its 4 x 4 operands, barrier, writes them back transposed, barrier.  Twiddles come from a table of
 // exp(-2 pi i m / L) computed in long double on the host.
@@ -42,10 +45,36 @@ __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
     return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
+// Optional padding of the LDS image by one complex per four (index c -> c + c/4): the first
+// radix-4 pass stores with a 64-byte lane stride (4-way ds_write_b128 bank conflict unpadded).
+#ifndef FFT_PAD
+#define FFT_PAD 0
+#endif
+#if FFT_PAD
+#define PADC(c) ((c) + ((c) >> 2))
+#else
+#define PADC(c) (c)
+#endif
+template <int C>
+struct FftLds {
+    static constexpr int SIZE = FFT_PAD ? C + C / 4 + 4 : C;
+};
+
 // In-place FFT of the NFFT = C/L sequences stored back to back in buf (C/16 threads).
+// threads per workgroup for an image of C complex doubles (tuning knob: C/16 = one butterfly
+// quartet per thread per pass; fewer butterflies per thread = more wavefronts per CU at equal LDS)
+#ifndef FFT_BPT
+#define FFT_BPT 2
+#endif
+template <int C>
+struct FftThreads {
+    static constexpr int T = C / (4 * FFT_BPT);
+};
+
 template <int C>
 __device__ __forceinline__ void fft_lds(double2 *buf, const FftAxis ax) {
-    constexpr int T = C / 16;
+    constexpr int T = FftThreads<C>::T;
+    constexpr int NB4 = C / (4 * T), NB2 = C / (2 * T);
     const int tid = threadIdx.x;
     const int L = ax.L, logL = ax.logL;
     int logNs = 0;
@@ -53,8 +82,8 @@ __device__ __forceinline__ void fft_lds(double2 *buf, const FftAxis ax) {
     const int logQ = logL - 2, Q = L >> 2;
     for (; logNs + 2 <= logL; logNs += 2) {
         const int Ns = 1 << logNs;
-        double2 v[4][4];
-        int wbase[4];
+        double2 v[NB4][4];
+        int wbase[NB4];
         // the twiddles depend on k = j mod Ns only; for Ns <= T all four butterflies of a thread
         // share them (j = tid + i T), so they are loaded once
         const bool shared_tw = Ns <= T;
@@ -66,11 +95,12 @@ __device__ __forceinline__ void fft_lds(double2 *buf, const FftAxis ax) {
             w3 = ax.tw[3 * ti];
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NB4; ++i) {
             const int idx = tid + i * T;
             const int f = idx >> logQ, j = idx & (Q - 1), k = j & (Ns - 1);
-            double2 *bp = buf + f * L;
-            double2 a = bp[j], b = bp[j + Q], c = bp[j + 2 * Q], d = bp[j + 3 * Q];
+            const int fb = f * L;
+            double2 a = buf[PADC(fb + j)], b = buf[PADC(fb + j + Q)], c = buf[PADC(fb + j + 2 * Q)],
+                    d = buf[PADC(fb + j + 3 * Q)];
             if (logNs > 0) {
                 if (!shared_tw) {
                     const int ti = k << (logL - logNs - 2);
@@ -93,30 +123,30 @@ __device__ __forceinline__ void fft_lds(double2 *buf, const FftAxis ax) {
         }
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NB4; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) buf[wbase[i] + r * Ns] = v[i][r];
+            for (int r = 0; r < 4; ++r) buf[PADC(wbase[i] + r * Ns)] = v[i][r];
         __syncthreads();
     }
     if (logNs < logL) {          // one radix-2 pass: C/2 butterflies = 8 per thread
         const int Ns = 1 << logNs, H = L >> 1, logH = logL - 1;
-        double2 v[8][2];
-        int wbase[8];
+        double2 v[NB2][2];
+        int wbase[NB2];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NB2; ++i) {
             const int idx = tid + i * T;
             const int f = idx >> logH, j = idx & (H - 1), k = j & (Ns - 1);
-            double2 *bp = buf + f * L;
-            double2 a = bp[j], b = cmul(bp[j + H], ax.tw[k << (logL - logNs - 1)]);
+            const int fb = f * L;
+            double2 a = buf[PADC(fb + j)], b = cmul(buf[PADC(fb + j + H)], ax.tw[k << (logL - logNs - 1)]);
             v[i][0] = make_double2(a.x + b.x, a.y + b.y);
             v[i][1] = make_double2(a.x - b.x, a.y - b.y);
             wbase[i] = f * L + ((j >> logNs) << (logNs + 1)) + k;
         }
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            buf[wbase[i]] = v[i][0];
-            buf[wbase[i] + Ns] = v[i][1];
+        for (int i = 0; i < NB2; ++i) {
+            buf[PADC(wbase[i])] = v[i][0];
+            buf[PADC(wbase[i] + Ns)] = v[i][1];
         }
         __syncthreads();
     }
@@ -125,13 +155,13 @@ __device__ __forceinline__ void fft_lds(double2 *buf, const FftAxis ax) {
 // E along the fast axis.  EPI 0: out = scale * E(in);  EPI 3: same + per-workgroup partial of
 // sum W (D[slot] - dbar) (other ? other : out) * out  into sp.gpart[b * gridDim.x + blockIdx.x].
 template <int EPI, int C>
-__global__ __launch_bounds__(C / 16) void k_dct_rows(Geom G, FftAxis ax, const double *__restrict__ in,
+__global__ __launch_bounds__(FftThreads<C>::T) void k_dct_rows(Geom G, FftAxis ax, const double *__restrict__ in,
                                                   long in_slot_stride, double *__restrict__ out, double scale,
                                                   SpecArgs sp, const TrajState *__restrict__ st, int gate) {
     const int b = blockIdx.z;
     if (gate && !st[b].lin_active) return;
-    __shared__ double2 buf[C];
-    constexpr int T = C / 16;
+    __shared__ double2 buf[FftLds<C>::SIZE];
+    constexpr int T = FftThreads<C>::T;
     const int tid = threadIdx.x;
     const int L = ax.L, N = ax.N, nfft = C >> ax.logL;
     const int row0 = blockIdx.x * 2 * nfft;
@@ -143,8 +173,8 @@ __global__ __launch_bounds__(C / 16) void k_dct_rows(Geom G, FftAxis ax, const d
         const int ra = row0 + 2 * f, rb = ra + 1;
         double2 v = make_double2(ra < G.ns ? ib[(long)ra * G.pitch + j] : 0.0,
                                  rb < G.ns ? ib[(long)rb * G.pitch + j] : 0.0);
-        buf[f * L + j] = v;
-        if (j > 0 && j < N) buf[f * L + L - j] = v;
+        buf[PADC(f * L + j)] = v;
+        if (j > 0 && j < N) buf[PADC(f * L + L - j)] = v;
     }
     __syncthreads();
     fft_lds<C>(buf, ax);
@@ -160,7 +190,7 @@ __global__ __launch_bounds__(C / 16) void k_dct_rows(Geom G, FftAxis ax, const d
         const int rr = (int)(((float)idx + 0.5f) * inv_n1), k = idx - rr * n1;
         const int row = row0 + rr;
         if (row < G.ns) {
-            const double2 c = buf[(rr >> 1) * L + k];
+            const double2 c = buf[PADC((rr >> 1) * L + k)];
             const double v = scale * ((rr & 1) ? c.y : c.x);
             const long o = (long)row * G.pitch + k;
             ob[o] = v;
@@ -183,13 +213,13 @@ __global__ __launch_bounds__(C / 16) void k_dct_rows(Geom G, FftAxis ax, const d
 
 // E along the slow axis, spectral multiplier 1/(c0 + m (c1 + c2 m)) (m = ms[k] + mf[col]), E again.
 template <int C>
-__global__ __launch_bounds__(C / 16) void k_dct_cols(Geom G, FftAxis ax, const double *__restrict__ in,
+__global__ __launch_bounds__(FftThreads<C>::T) void k_dct_cols(Geom G, FftAxis ax, const double *__restrict__ in,
                                                   double *__restrict__ out, double scale, SpecArgs sp,
                                                   const TrajState *__restrict__ st, int gate) {
     const int b = blockIdx.z;
     if (gate && !st[b].lin_active) return;
-    __shared__ double2 buf[C];
-    constexpr int T = C / 16;
+    __shared__ double2 buf[FftLds<C>::SIZE];
+    constexpr int T = FftThreads<C>::T;
     const int tid = threadIdx.x;
     const int L = ax.L, N = ax.N, nfft = C >> ax.logL, ncol = 2 * nfft;
     const int col0 = xcd_remap(blockIdx.x, gridDim.x) * ncol;
@@ -203,8 +233,8 @@ __global__ __launch_bounds__(C / 16) void k_dct_cols(Geom G, FftAxis ax, const d
         const int col = col0 + cc;
         const double v = col < G.nf ? ib[(long)r * G.pitch + col] : 0.0;
         const int f = cc >> 1, comp = cc & 1;
-        sb[2 * (f * L + r) + comp] = v;
-        if (r > 0 && r < N) sb[2 * (f * L + L - r) + comp] = v;
+        sb[2 * PADC(f * L + r) + comp] = v;
+        if (r > 0 && r < N) sb[2 * PADC(f * L + L - r) + comp] = v;
     }
     __syncthreads();
     fft_lds<C>(buf, ax);
@@ -214,11 +244,11 @@ __global__ __launch_bounds__(C / 16) void k_dct_cols(Geom G, FftAxis ax, const d
         const int ks = k <= N ? k : L - k;
         const int ca = col0 + 2 * f, cb = ca + 1;
         const double msk = sp.ms[ks];
-        double2 v = buf[idx];
+        double2 v = buf[PADC(idx)];
         double ma = msk + sp.mf[ca < G.nf ? ca : G.nf - 1], mb = msk + sp.mf[cb < G.nf ? cb : G.nf - 1];
         v.x *= scale / (sp.c0 + ma * (c1 + sp.c2 * ma));
         v.y *= scale / (sp.c0 + mb * (c1 + sp.c2 * mb));
-        buf[idx] = v;
+        buf[PADC(idx)] = v;
     }
     __syncthreads();
     fft_lds<C>(buf, ax);
@@ -226,6 +256,6 @@ __global__ __launch_bounds__(C / 16) void k_dct_cols(Geom G, FftAxis ax, const d
     for (int idx = tid; idx < n1 * ncol; idx += T) {
         const int r = idx >> lc, cc = idx & (ncol - 1);
         const int col = col0 + cc;
-        if (col < G.nf) ob[(long)r * G.pitch + col] = sb[2 * ((cc >> 1) * L + r) + (cc & 1)];
+        if (col < G.nf) ob[(long)r * G.pitch + col] = sb[2 * PADC((cc >> 1) * L + r) + (cc & 1)];
     }
 }
