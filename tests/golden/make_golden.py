@@ -283,6 +283,25 @@ def gen_2d(big=False):
     # huge step: optimistic step overshoots -> backtracking engages (G2:320-328)
     pgd_case("16_bt", 16, 0.1, 1e-2, 4.0e4, 3)
 
+    # ---- 8. second-order / sparsity diagnostics on the PGD result (G2:424-437, S2) -------
+    S2 = importlib.import_module("second_order_conditions_2d")
+    gp = np.load(os.path.join(HERE, "g2d_pgd_16.npz"))
+    cfg = K2.ForwardSolverConfig(Nx=16, Ny=16, T=float(gp["T"]), dt_initial=float(gp["dt"]))
+    opt = K2.OptimizationConfig()
+    x = np.linspace(0, 1, 17); y = np.linspace(0, 1, 17)
+    with quiet():
+        _, _, r_opt = B2.run_backward(gp["phi_final"], x, y, gp["t_hist"], cfg, opt.b1, opt.b2, gp["phi_Q"], gp["phi_T"])
+        d2 = S2.approximate_second_order_condition_2d(
+            u_star=gp["u_final"], r_star=r_opt, phi_star=gp["phi_final"], x=x, y=y, t_hist=gp["t_hist"],
+            b1=opt.b1, b2=opt.b2, b3=opt.b3, kappa=opt.kappa_sparsity, phi_Q_target=gp["phi_Q"],
+            phi_T_target=gp["phi_T"], u_min=opt.u_min, u_max=opt.u_max, num_directions=3, epsilon=1e-4, seed=42,
+            fwd_config=cfg)
+    rng = np.random.default_rng(42)
+    h0 = S2._generate_direction(gp["u_final"], r_opt, opt.u_min, opt.u_max, rng)
+    usat = gp["u_final"].copy(); usat.flat[::7] = 1.0; usat.flat[3::11] = -1.0
+    hs = S2._generate_direction(usat, r_opt, opt.u_min, opt.u_max, np.random.default_rng(7))
+    save("g2d_soc_16.npz", r_opt=r_opt, d2=np.array(d2), h0=h0, u_sat=usat, h_sat=hs)
+
     if big:
         # Full-size spot check: residual-norm histories of the first two 512^2 steps
         # (the round-off-limited regime of SURVEY 7 'hard parts') + sub-sampled fields.
@@ -463,6 +482,20 @@ def gen_1d():
 
     pgd_case("32", 32, 0.1, 1e-2, 100.0, 4)
     pgd_case("32_bt", 32, 0.1, 1e-2, 2.0e5, 3)
+
+    # second-order / sparsity diagnostics on the PGD result (G1:493-518, S1)
+    S1 = importlib.import_module("second_order_conditions")
+    gp = np.load(os.path.join(HERE, "g1d_pgd_32.npz"))
+    cfg = K1.ForwardSolverConfig(N=32, T=float(gp["T"]), dt_initial=float(gp["dt"]))
+    opt = K1.OptimizationConfig()
+    x = np.linspace(0, 1, 33)
+    with quiet():
+        _, _, r_opt = B1.run_backward(gp["phi_final"], x, gp["t_hist"], opt.b1, opt.b2, gp["phi_Q"], gp["phi_T"])
+        d2 = S1.approximate_second_order_condition(cfg, gp["u_final"], r_opt, gp["phi_final"], x, gp["t_hist"],
+                                                   opt.b1, opt.b2, opt.b3, opt.kappa_sparsity, gp["phi_Q"], gp["phi_T"],
+                                                   opt.u_min, opt.u_max, num_directions=3, epsilon=1e-4, seed=42)
+    h0 = S1._generate_direction(gp["u_final"], r_opt, opt.u_min, opt.u_max, opt.kappa_sparsity, opt.b3, np.random.default_rng(42))
+    save("g1d_soc_32.npz", r_opt=r_opt, d2=np.array(d2), h0=h0)
 
     N = 4096
     cfg = K1.ForwardSolverConfig(N=N)

@@ -106,3 +106,40 @@ def test_1d_function_seam_and_driver(V):
         assert relerr(res["u"], gp["u_final"]) < 1e-8
     st = G1.verify_sparsity_condition(res["u"], res["r"], optp.kappa_sparsity, verbose=False)
     assert 0.0 <= st[2] <= 100.0
+
+
+def test_second_order_and_sparsity_diagnostics(V):
+    """the coercivity finite-difference test and the KKT sparsity statistic,
+    run through the mirrored modules on the GPU, against the reference's own numbers."""
+    S2 = V.module("Vch_control_2D.second_order_conditions_2d")
+    K2 = V.module("Vch_control_2D.config")
+    B2 = V.module("Vch_control_2D.backward2_solver")
+    gp, gs = golden("g2d_pgd_16.npz"), golden("g2d_soc_16.npz")
+    cfg = K2.ForwardSolverConfig(Nx=16, Ny=16, T=float(gp["T"]), dt_initial=float(gp["dt"]))
+    opt = K2.OptimizationConfig()
+    x = y = np.linspace(0, 1, 17)
+    _, _, r_opt = B2.run_backward(gp["phi_final"], x, y, gp["t_hist"], cfg, opt.b1, opt.b2, gp["phi_Q"], gp["phi_T"])
+    assert relerr(r_opt, gs["r_opt"]) < 1e-9
+    assert np.array_equal(S2._generate_direction(gp["u_final"], gs["r_opt"], opt.u_min, opt.u_max, np.random.default_rng(42)), gs["h0"])
+    assert np.array_equal(S2._generate_direction(gs["u_sat"], gs["r_opt"], opt.u_min, opt.u_max, np.random.default_rng(7)), gs["h_sat"])
+    with contextlib.redirect_stdout(io.StringIO()):
+        d2 = S2.approximate_second_order_condition_2d(
+            u_star=gp["u_final"], r_star=gs["r_opt"], phi_star=gp["phi_final"], x=x, y=y, t_hist=gp["t_hist"], b1=opt.b1,
+            b2=opt.b2, b3=opt.b3, kappa=opt.kappa_sparsity, phi_Q_target=gp["phi_Q"], phi_T_target=gp["phi_T"],
+            u_min=opt.u_min, u_max=opt.u_max, num_directions=3, epsilon=1e-4, seed=42, fwd_config=cfg)
+        st = S2.verify_sparsity_condition(gp["u_final"], gs["r_opt"], opt.kappa_sparsity)
+    assert np.allclose(d2, gs["d2"], rtol=1e-5), (d2, gs["d2"])
+    assert 0 <= st[2] <= 100
+    # 1D
+    S1 = V.module("Vch_control_1D.second_order_conditions")
+    K1 = V.module("Vch_control_1D.config")
+    gp, gs = golden("g1d_pgd_32.npz"), golden("g1d_soc_32.npz")
+    cfg = K1.ForwardSolverConfig(N=32, T=float(gp["T"]), dt_initial=float(gp["dt"]))
+    o = K1.OptimizationConfig()
+    x = np.linspace(0, 1, 33)
+    assert np.array_equal(S1._generate_direction(gp["u_final"], gs["r_opt"], o.u_min, o.u_max, o.kappa_sparsity, o.b3,
+                                                 np.random.default_rng(42)), gs["h0"])
+    d2 = S1.approximate_second_order_condition(cfg, gp["u_final"], gs["r_opt"], gp["phi_final"], x, gp["t_hist"], o.b1, o.b2,
+                                               o.b3, o.kappa_sparsity, gp["phi_Q"], gp["phi_T"], o.u_min, o.u_max,
+                                               num_directions=3, epsilon=1e-4, seed=42)
+    assert np.allclose(d2, gs["d2"], rtol=1e-5), (d2, gs["d2"])

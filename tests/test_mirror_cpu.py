@@ -49,6 +49,9 @@ def test_mirror_exposes_reference_names(V):
         "Vch_control_2D.backward2_solver": ["fpp_log", "run_backward"],
         "Vch_control_2D.cost2_and_function": ["calculate_cost", "calculate_gradient", "proximal_step"],
         "Vch_control_2D.GD2_configured": ["perform_backtracking_line_search_2D", "build_targets"],
+        "Vch_control_2D.second_order_conditions_2d": ["approximate_second_order_condition_2d", "verify_sparsity_condition",
+                                                      "_generate_direction"],
+        "Vch_control_1D.second_order_conditions": ["approximate_second_order_condition", "_generate_direction"],
         "Vch_control_1D.Forward_solver": ["regularized_log", "laplacian_matrix_neumann", "apply_laplacian", "initialize_mu",
                                           "solve_w", "solve_mu_residual", "solve_phi_residual", "assemble_jacobian",
                                           "newton_raphson", "trapz_weights", "free_energy", "init_phi_random",
@@ -74,3 +77,17 @@ def test_host_helpers_match_oracle(V):
     phi = np.random.default_rng(0).uniform(-0.99, 0.99, (9, 7))
     assert np.array_equal(F2.regularized_log(phi, 1e-2), O2.reg_log(phi))
     assert abs(F2.free_energy(phi, 1e-4, 0.75, 1.0, 0.1, 0.2) - O2.free_energy(phi, 1e-4, 0.75, 1.0, 0.1, 0.2)) < 1e-14
+
+
+def test_direction_generators_match_reference_goldens(V):
+    """The critical-cone direction generators are host logic (NumPy RNG stream): bit-exact."""
+    import numpy as np
+    from conftest import golden
+    S2 = V.module("Vch_control_2D.second_order_conditions_2d")
+    S1 = V.module("Vch_control_1D.second_order_conditions")
+    gp, gs = golden("g2d_pgd_16.npz"), golden("g2d_soc_16.npz")
+    assert np.array_equal(S2._generate_direction(gp["u_final"], gs["r_opt"], -1.0, 1.0, np.random.default_rng(42)), gs["h0"])
+    assert np.array_equal(S2._generate_direction(gs["u_sat"], gs["r_opt"], -1.0, 1.0, np.random.default_rng(7)), gs["h_sat"])
+    gp, gs = golden("g1d_pgd_32.npz"), golden("g1d_soc_32.npz")
+    assert np.array_equal(S1._generate_direction(gp["u_final"], gs["r_opt"], -1.0, 1.0, 0.00009, 0.0019,
+                                                 np.random.default_rng(42)), gs["h0"])
