@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--grid", type=int, default=512, help="Nx = Ny")
     ap.add_argument("--time-steps", type=int, default=1000)
     ap.add_argument("--batch-per-gpu", type=int, default=8)
+    ap.add_argument("--contexts", type=int, default=2,
+                    help="engine contexts (HIP streams, one host thread each) the per-GPU batch is split over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-grid", type=int, default=None, help="grid of the CPU sample (default: --grid)")
@@ -112,7 +114,11 @@ def main():
     dt = T / M
     t_hist, dts = vch_amd.time_grid(T, dt)
     M = len(dts)
-    eng = vch_amd.Engine2D(Nx=N, Ny=N, batch=B, max_steps=M, device=local)
+    K = max(1, a.contexts)
+    assert B % K == 0, "--batch-per-gpu must be divisible by --contexts"
+    Bc = B // K
+    engs = [vch_amd.Engine2D(Nx=N, Ny=N, batch=Bc, max_steps=M, device=local) for _ in range(K)]
+    eng = engs[0]
     par = vch_amd.parallel
     dev = f"cuda:{local}" if dist is not None else "cpu"
     seeds = par.shard_seeds(rank, max(world, 1), B)
@@ -120,9 +126,23 @@ def main():
     xs = np.linspace(0.0, 1.0, N + 1)
     phi_T = 0.7 * np.sin(2 * np.pi * xs)[:, None] * np.cos(np.pi * xs)[None, :]       # G2:199
     opt = vch_amd.make_opt()
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max_workers=K)
+
+    def on_all(fn):
+        """run fn(k, engine) for every context concurrently (ctypes releases the GIL)"""
+        return list(pool.map(lambda ke: fn(*ke), enumerate(engs)))
+
     t_init = time.perf_counter()
-    J0 = eng.pgd_init(phi0, np.broadcast_to(phi_T, phi0.shape).copy(), t_hist, opt, ramp=True, T=T)
+    J0 = np.concatenate(on_all(lambda k, e: e.pgd_init(
+        phi0[k * Bc:(k + 1) * Bc], np.broadcast_to(phi_T, (Bc,) + phi_T.shape).copy(), t_hist, opt, ramp=True, T=T)))
     t_init = time.perf_counter() - t_init
+
+    def pgd_step():
+        rs = on_all(lambda k, e: e.pgd_iterate(1))
+        r = dict(cost=np.concatenate([x["cost"] for x in rs]), attempts=np.concatenate([x["attempts"] for x in rs]),
+                 seconds={k: max(x["seconds"][k] for x in rs) for k in rs[0]["seconds"]})
+        return r
 
     def step_costs(r):
         """[B][5] costs of this rank after an iteration: total from the engine, parts not needed"""
@@ -132,14 +152,14 @@ def main():
 
     costs = []
     for _ in range(a.warmup):
-        r = eng.pgd_iterate(1)
+        r = pgd_step()
         par.allreduce_cost(step_costs(r), dist, dev)
     par.barrier(dist, dev)
     t0 = time.perf_counter()
     buckets = {}
     attempts = 0
     for _ in range(a.steps):
-        r = eng.pgd_iterate(1)                  # synchronous: returns when the device is done
+        r = pgd_step()                          # synchronous: returns when the device is done
         Jsum = par.allreduce_cost(step_costs(r), dist, dev)      # the single RCCL collective of an iteration
         costs.append(float(Jsum[4]))
         attempts += int(r["attempts"].sum())
@@ -156,12 +176,12 @@ def main():
         eng.prof_begin(400000)
         eng.pgd_iterate(1)
         prof = eng.prof_end()
-        nodes = (N + 1) * (N + 1) * B
+        nodes = (N + 1) * (N + 1) * Bc
         alg = {  # algorithmic bytes / flops per launch
             "schur_p": ("hbm", 40.0 * nodes), "adj_q": ("hbm", 32.0 * nodes), "residual": ("hbm", 88.0 * nodes),
             "cg_update": ("hbm", 48.0 * nodes), "adj_rhs": ("hbm", 72.0 * nodes),
             # DCT preconditioner: three FFT passes (field in, field out) or four MFMA f64 GEMMs
-            "dct": ("hbm", 16.0 * nodes) if eng.uses_fft else ("mfma", 2.0 * (N + 1) ** 3 * B),
+            "dct": ("hbm", 16.0 * nodes) if eng.uses_fft else ("mfma", 2.0 * (N + 1) ** 3 * Bc),
         }
         tot = {k: v["ms"] for k, v in prof.items()}
         dom = max(tot, key=tot.get)
@@ -196,14 +216,15 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"2D {N}x{N}, {M} time steps, batch {B} trajectories per GPU "
                                    f"({total_traj} total), seeds 42+i, targets build_targets 1/1, u0 = 0",
-                       "grid": N, "time_steps": M, "batch_per_gpu": B, "parallelism": f"batch-shard x{max(world, 1)}"},
+                       "grid": N, "time_steps": M, "batch_per_gpu": B, "contexts_per_gpu": K, "parallelism": f"batch-shard x{max(world, 1)}"},
             "roofline": roof, "cpu_baseline": cpu,
             "init_s": t_init, "J0_sum": float(J0[:, 4].sum()), "cost_sum_per_step": costs,
             "backtracking_forwards": attempts, "time_buckets_s": buckets,
         }
         out.update(extra)
         print(json.dumps(out))
-    eng.close()
+    for e in engs:
+        e.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -219,6 +219,7 @@ extern "C" vch2d_ctx *vch2d_create(const vch2d_params *p, int batch, int max_ste
     c->prof_used = 0;
     c->lin_maxit = 4000;
     c->lin_tol = 1e-15;
+    if (const char *e = getenv("VCH_LIN_TOL")) c->lin_tol = atof(e);      // tuning/experiments only
     auto fail = [&](const char *what) {
         vch_fail(VCH_ERR_HIP, "vch2d_create: %s failed: %s", what, hipGetErrorString(hipGetLastError()));
         return (vch2d_ctx *)nullptr;
