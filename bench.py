@@ -106,7 +106,7 @@ def main():
         torch.cuda.set_device(local)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
     import vch_amd
-    from oracle import vch2d_oracle as O2     # init_phi_random only (seeded initial data + targets)
+    F2 = vch_amd.module("Vch_control_2D.Forward2_solver")      # init_phi_random: the package's own host function
 
     vch_amd.build()
     N, M, B = a.grid, a.time_steps, a.batch_per_gpu
@@ -122,7 +122,7 @@ def main():
     par = vch_amd.parallel
     dev = f"cuda:{local}" if dist is not None else "cpu"
     seeds = par.shard_seeds(rank, max(world, 1), B)
-    phi0 = np.stack([O2.init_phi_random(N, N, 1e-2, amp=0.1, seed=s) for s in seeds])
+    phi0 = np.stack([F2.init_phi_random(N, N, 1e-2, amp=0.1, seed=s) for s in seeds])
     xs = np.linspace(0.0, 1.0, N + 1)
     phi_T = 0.7 * np.sin(2 * np.pi * xs)[:, None] * np.cos(np.pi * xs)[None, :]       # G2:199
     opt = vch_amd.make_opt()

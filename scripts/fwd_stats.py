@@ -4,7 +4,7 @@ import sys, time
 import numpy as np
 sys.path.insert(0, ".")
 import vch_amd
-from oracle import vch2d_oracle as O2
+O2 = vch_amd.module("Vch_control_2D.Forward2_solver")
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 M = int(sys.argv[2]) if len(sys.argv) > 2 else 200
