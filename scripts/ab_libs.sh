@@ -8,7 +8,7 @@ mkdir -p gpurun_out/ab
 for TAG in "$@"; do
   export VCH_LIB=$PWD/$PK/libvch_$TAG.so
   rm -rf gpurun_out/ab/$TAG
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ab/$TAG -- python bench.py --steps 1 --warmup 0 --time-steps 100 --no-cpu-baseline --no-roofline > gpurun_out/ab/$TAG.json 2> gpurun_out/ab/$TAG.err || { tail -5 gpurun_out/ab/$TAG.err; continue; }
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ab/$TAG -- python bench.py --steps 1 --warmup 0 --time-steps 100 --no-cpu-baseline --no-roofline --contexts 1 > gpurun_out/ab/$TAG.json 2> gpurun_out/ab/$TAG.err || { tail -5 gpurun_out/ab/$TAG.err; continue; }
   find gpurun_out/ab/$TAG -name "*kernel_trace*" -delete
   echo "== $TAG"; python - <<PY
 import json,glob,csv

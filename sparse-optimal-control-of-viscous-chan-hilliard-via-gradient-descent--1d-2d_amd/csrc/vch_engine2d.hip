@@ -356,32 +356,33 @@ static int precond(vch2d_ctx *c, const double *in, long in_slot_stride, double *
     if (c->use_fft) {
         const double scale = 1.0 / (4.0 * (double)c->fax.N * (double)c->sax.N);
         // C = complex doubles per workgroup: 1024 (one wavefront) unless the FFT is longer
-#define DCT_ROWS(EPI_, C_, in_, iss_, out_)                                                                     \
+#define DCT_ROWS(EPI_, C_, LG_, in_, iss_, out_)                                                                \
     do {                                                                                                        \
         const int rpw = 2 * (C_ >> c->fax.logL);                                                                \
-        LAUNCHC(PC_GEMM, (k_dct_rows<EPI_, C_>), dim3((ns + rpw - 1) / rpw, 1, c->B), dim3(FftThreads<C_>::T), G, c->fax, \
-                in_, iss_, out_, 1.0, sp, c->st, gate);                                                         \
+        LAUNCHC(PC_GEMM, (k_dct_rows<EPI_, C_, LG_>), dim3((ns + rpw - 1) / rpw, 1, c->B), dim3(FftThreads<C_>::T), G, \
+                c->fax, in_, iss_, out_, 1.0, sp, c->st, gate);                                                 \
     } while (0)
-#define DCT_COLS(C_)                                                                                            \
+#define DCT_COLS(C_, LG_)                                                                                       \
     do {                                                                                                        \
         const int cpw = 2 * (C_ >> c->sax.logL);                                                                \
-        LAUNCHC(PC_GEMM, (k_dct_cols<C_>), dim3((nf + cpw - 1) / cpw, 1, c->B), dim3(FftThreads<C_>::T), G, c->sax,       \
-                (const double *)c->t1, c->t2, scale, sp, c->st, gate);                                          \
+        LAUNCHC(PC_GEMM, (k_dct_cols<C_, LG_>), dim3((nf + cpw - 1) / cpw, 1, c->B), dim3(FftThreads<C_>::T), G, \
+                c->sax, (const double *)c->t1, c->t2, scale, sp, c->st, gate);                                  \
     } while (0)
-#define DCT_ROWS_ANY(EPI_, in_, iss_, out_)                                  \
-    do {                                                                     \
-        if (c->fax.L <= 1024) DCT_ROWS(EPI_, 1024, in_, iss_, out_);         \
-        else if (c->fax.L == 2048) DCT_ROWS(EPI_, 2048, in_, iss_, out_);    \
-        else DCT_ROWS(EPI_, 4096, in_, iss_, out_);                          \
+        // FFT lengths 512 / 1024 / 2048 (grids 256^2, 512^2, 1024^2) are compiled with a constant length
+#define DCT_ROWS_ANY(EPI_, in_, iss_, out_)                                       \
+    do {                                                                          \
+        if (c->fax.logL == 10) DCT_ROWS(EPI_, 1024, 10, in_, iss_, out_);         \
+        else if (c->fax.logL == 9) DCT_ROWS(EPI_, 1024, 9, in_, iss_, out_);      \
+        else if (c->fax.logL < 10) DCT_ROWS(EPI_, 1024, 0, in_, iss_, out_);      \
+        else if (c->fax.logL == 11) DCT_ROWS(EPI_, 2048, 11, in_, iss_, out_);    \
+        else DCT_ROWS(EPI_, 4096, 0, in_, iss_, out_);                            \
     } while (0)
         DCT_ROWS_ANY(0, in, in_slot_stride, c->t1);
-        {
-            static const int colsC = getenv("VCH_DCT_COLS_C") ? atoi(getenv("VCH_DCT_COLS_C")) : 0;   // tuning knob
-            const int Cc = std::max(colsC ? colsC : 1024, c->sax.L);
-            if (Cc <= 1024) DCT_COLS(1024);
-            else if (Cc == 2048) DCT_COLS(2048);
-            else DCT_COLS(4096);
-        }
+        if (c->sax.logL == 10) DCT_COLS(1024, 10);
+        else if (c->sax.logL == 9) DCT_COLS(1024, 9);
+        else if (c->sax.logL < 10) DCT_COLS(1024, 0);
+        else if (c->sax.logL == 11) DCT_COLS(2048, 11);
+        else DCT_COLS(4096, 0);
         if (last == 3) DCT_ROWS_ANY(3, (const double *)c->t2, 0L, out);
         else DCT_ROWS_ANY(0, (const double *)c->t2, 0L, out);
         return 0;

@@ -71,15 +71,18 @@ struct FftThreads {
     static constexpr int T = C / (4 * FFT_BPT);
 };
 
-template <int C>
+// LOGL > 0: log2 of the FFT length is a compile-time constant (all index arithmetic folds and the
+// pass loop unrolls; the kernels are VALU-issue bound, so this matters); LOGL = 0: run-time length.
+template <int C, int LOGL>
 __device__ __forceinline__ void fft_lds(double2 *buf, const FftAxis ax) {
     constexpr int T = FftThreads<C>::T;
     constexpr int NB4 = C / (4 * T), NB2 = C / (2 * T);
     const int tid = threadIdx.x;
-    const int L = ax.L, logL = ax.logL;
+    const int logL = LOGL ? LOGL : ax.logL, L = 1 << logL;
     int logNs = 0;
     // radix-4 passes: C/4 butterflies = 4 per thread
     const int logQ = logL - 2, Q = L >> 2;
+#pragma unroll
     for (; logNs + 2 <= logL; logNs += 2) {
         const int Ns = 1 << logNs;
         double2 v[NB4][4];
@@ -154,7 +157,7 @@ __device__ __forceinline__ void fft_lds(double2 *buf, const FftAxis ax) {
 
 // E along the fast axis.  EPI 0: out = scale * E(in);  EPI 3: same + per-workgroup partial of
 // sum W (D[slot] - dbar) (other ? other : out) * out  into sp.gpart[b * gridDim.x + blockIdx.x].
-template <int EPI, int C>
+template <int EPI, int C, int LOGL>
 __global__ __launch_bounds__(FftThreads<C>::T) void k_dct_rows(Geom G, FftAxis ax, const double *__restrict__ in,
                                                   long in_slot_stride, double *__restrict__ out, double scale,
                                                   SpecArgs sp, const TrajState *__restrict__ st, int gate) {
@@ -163,13 +166,13 @@ __global__ __launch_bounds__(FftThreads<C>::T) void k_dct_rows(Geom G, FftAxis a
     __shared__ double2 buf[FftLds<C>::SIZE];
     constexpr int T = FftThreads<C>::T;
     const int tid = threadIdx.x;
-    const int L = ax.L, N = ax.N, nfft = C >> ax.logL;
+    const int logL = LOGL ? LOGL : ax.logL, L = 1 << logL, N = L >> 1, nfft = C >> logL;
     const int row0 = blockIdx.x * 2 * nfft;
     const double *ib = in + b * G.plane + (in_slot_stride ? st[b].slot * in_slot_stride : 0);
     const int n1 = N + 1;
     const float inv_n1 = 1.0f / (float)n1;       // idx < 2^14: the float quotient is exact enough
     for (int idx = tid; idx < nfft * n1; idx += T) {
-        const int f = (int)(((float)idx + 0.5f) * inv_n1), j = idx - f * n1;
+        const int f = nfft == 1 ? 0 : (int)(((float)idx + 0.5f) * inv_n1), j = idx - f * n1;
         const int ra = row0 + 2 * f, rb = ra + 1;
         double2 v = make_double2(ra < G.ns ? ib[(long)ra * G.pitch + j] : 0.0,
                                  rb < G.ns ? ib[(long)rb * G.pitch + j] : 0.0);
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(FftThreads<C>::T) void k_dct_rows(Geom G, FftAxis a
         if (j > 0 && j < N) buf[PADC(f * L + L - j)] = v;
     }
     __syncthreads();
-    fft_lds<C>(buf, ax);
+    fft_lds<C, LOGL>(buf, ax);
     double dot = 0.0, dbar = 0.0;
     const double *Dp = nullptr, *Ob = nullptr;
     if (EPI == 3) {
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(FftThreads<C>::T) void k_dct_rows(Geom G, FftAxis a
     }
     double *ob = out + b * G.plane;
     for (int idx = tid; idx < 2 * nfft * n1; idx += T) {
-        const int rr = (int)(((float)idx + 0.5f) * inv_n1), k = idx - rr * n1;
+        const int rr = nfft == 1 ? (idx >= n1 ? 1 : 0) : (int)(((float)idx + 0.5f) * inv_n1), k = idx - rr * n1;
         const int row = row0 + rr;
         if (row < G.ns) {
             const double2 c = buf[PADC((rr >> 1) * L + k)];
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(FftThreads<C>::T) void k_dct_rows(Geom G, FftAxis a
 }
 
 // E along the slow axis, spectral multiplier 1/(c0 + m (c1 + c2 m)) (m = ms[k] + mf[col]), E again.
-template <int C>
+template <int C, int LOGL>
 __global__ __launch_bounds__(FftThreads<C>::T) void k_dct_cols(Geom G, FftAxis ax, const double *__restrict__ in,
                                                   double *__restrict__ out, double scale, SpecArgs sp,
                                                   const TrajState *__restrict__ st, int gate) {
@@ -221,7 +224,7 @@ __global__ __launch_bounds__(FftThreads<C>::T) void k_dct_cols(Geom G, FftAxis a
     __shared__ double2 buf[FftLds<C>::SIZE];
     constexpr int T = FftThreads<C>::T;
     const int tid = threadIdx.x;
-    const int L = ax.L, N = ax.N, nfft = C >> ax.logL, ncol = 2 * nfft;
+    const int logL = LOGL ? LOGL : ax.logL, L = 1 << logL, N = L >> 1, nfft = C >> logL, ncol = 2 * nfft;
     const int col0 = xcd_remap(blockIdx.x, gridDim.x) * ncol;
     const double *ib = in + b * G.plane;
     double *sb = reinterpret_cast<double *>(buf);
@@ -237,10 +240,10 @@ __global__ __launch_bounds__(FftThreads<C>::T) void k_dct_cols(Geom G, FftAxis a
         if (r > 0 && r < N) sb[2 * PADC(f * L + L - r) + comp] = v;
     }
     __syncthreads();
-    fft_lds<C>(buf, ax);
+    fft_lds<C, LOGL>(buf, ax);
     const double c1 = sp.c1a + sp.c1b * st[b].dbar;
     for (int idx = tid; idx < nfft * L; idx += T) {
-        const int f = idx >> ax.logL, k = idx & (L - 1);
+        const int f = idx >> logL, k = idx & (L - 1);
         const int ks = k <= N ? k : L - k;
         const int ca = col0 + 2 * f, cb = ca + 1;
         const double msk = sp.ms[ks];
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(FftThreads<C>::T) void k_dct_cols(Geom G, FftAxis a
         buf[PADC(idx)] = v;
     }
     __syncthreads();
-    fft_lds<C>(buf, ax);
+    fft_lds<C, LOGL>(buf, ax);
     double *ob = out + b * G.plane;
     for (int idx = tid; idx < n1 * ncol; idx += T) {
         const int r = idx >> lc, cc = idx & (ncol - 1);
