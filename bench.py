@@ -108,7 +108,12 @@ def main():
     import vch_amd
     F2 = vch_amd.module("Vch_control_2D.Forward2_solver")      # init_phi_random: the package's own host function
 
-    vch_amd.build()
+    if dist is None:
+        vch_amd.build()
+    else:                       # one builder per node, the other ranks wait (no concurrent hipcc into one .so)
+        if local == 0:
+            vch_amd.build()
+        dist.barrier()
     N, M, B = a.grid, a.time_steps, a.batch_per_gpu
     T = 1.0
     dt = T / M

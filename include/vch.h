@@ -63,7 +63,7 @@ typedef struct vch_opt_params {
 typedef struct vch_stats {
     int64_t newton_iters;      /* residual evaluations that entered the Newton loop (len(hist)) */
     int64_t linear_solves;     /* Newton linear solves (spsolve calls in the reference, F2:370) */
-    int64_t linear_iters;      /* preconditioned-Richardson sweeps spent in them */
+    int64_t linear_iters;      /* preconditioned CG iterations spent in them */
     int64_t armijo_trials;     /* residual evaluations in the Armijo loop (F2:398-419) */
     double  max_lin_relres;    /* worst final relative residual of a linear solve */
     double  seconds;           /* device time of the call (HIP events) */
@@ -101,7 +101,7 @@ int vch2d_jacobian_apply(vch2d_ctx *ctx, const double *phi_new, double dt, const
                          const double *dmu, double *out_phi, double *out_mu);
 /* Solve J(phi_new) [dphi; dmu] = [rhs_phi; rhs_mu].  Replaces spsolve(J.tocsc(), -R)
  * (F2:370): Schur reduction to the scalar 13-point system + DCT-I preconditioned
- * Richardson.  stats may be NULL. */
+ * conjugate gradients in the weighted inner product.  stats may be NULL. */
 int vch2d_jacobian_solve(vch2d_ctx *ctx, const double *phi_new, double dt, const double *rhs_phi,
                          const double *rhs_mu, double *dphi, double *dmu, vch_stats *stats);
 /* out = (I/dt + M(kappa/2 M + D)) x, the Schur-reduced Newton operator (M = -L). */

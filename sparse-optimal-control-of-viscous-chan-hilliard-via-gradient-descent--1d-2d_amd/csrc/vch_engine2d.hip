@@ -814,10 +814,6 @@ extern "C" int vch2d_forward(vch2d_ctx *c, const double *phi0, const double *u, 
 // ------------------------------------------------------------------------------------
 // adjoint sweep (B2:75-246)
 // ------------------------------------------------------------------------------------
-struct RampArgs {
-    const double *phi0, *phiT, *tfrac;   // device
-};
-
 // phi history in phi_hist_dev ([B][Mmax+1][plane]); targets phiQ_dev (same layout) or NULL, phiT_dev [B][plane] or NULL.
 static int backward_core(vch2d_ctx *c, const double *phi_hist_dev, int M, const double *t_hist, double b1, double b2,
                          const double *phiQ_dev, const double *phiT_dev, double *r_out, double *p_out, double *q_out) {

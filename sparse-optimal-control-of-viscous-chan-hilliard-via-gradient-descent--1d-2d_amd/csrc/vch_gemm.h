@@ -7,8 +7,8 @@
 // dense matrix products with precomputed matrices Q1 = S C^ and Q2 = C^ S^-1 (C^ the
 // orthonormal symmetric DCT-I matrix, S = diag(1/sqrt2,1,...,1,1/sqrt2)):
 //     z = Q2s^T [ mult o (Q1s^T (g Q1f)) ] Q2f            (g = plane viewed as ns x nf)
-// i.e. four GEMMs per application, the spectral multiplier fused into the second one and
-// the Richardson update x += z fused into the last one.
+// i.e. four GEMMs per application, the spectral multiplier fused into the second one and the
+// weighted dot product that CG needs next fused into the last one (EPI 3).
 //
 // Tiling: 64x64 output tile per 256-thread workgroup (4 wavefronts as 2x2, each 32x32 =
 // 2x2 MFMA tiles of 16x16), K advanced 16 at a time through LDS.  MFMA operand layout for

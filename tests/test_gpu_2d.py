@@ -3,7 +3,7 @@
  (b) the CPU oracle (oracle/vch2d_oracle.py) on seeded inputs at sizes it finishes in seconds.
 
 Tolerances (float64; the reference solves its linear systems with SuperLU, the engine with a
-DCT-preconditioned Richardson iteration converged to round-off, so results agree to solver
+DCT-preconditioned conjugate-gradient iteration converged to round-off, so results agree to solver
 round-off, not bit for bit):
   OPS   1e-12  pure stencil / element-wise arithmetic (different summation order only)
   SOLVE 1e-9   anything that passed through a linear solve or a short time march
