@@ -44,20 +44,36 @@ def _eng(V, g=None, B=1, max_steps=16, **kw):
 # ---------------------------------------------------------------------------------------
 # kernel level
 # ---------------------------------------------------------------------------------------
-@pytest.mark.parametrize("shape", [(16, 16, 1.0, 1.0), (12, 9, 1.0, 0.7), (70, 45, 1.3, 0.9), (129, 64, 1.0, 1.0)])
+@pytest.mark.parametrize("shape", [(16, 16, 1.0, 1.0), (12, 9, 1.0, 0.7), (70, 45, 1.3, 0.9), (129, 64, 1.0, 1.0),
+                                   (128, 128, 1.0, 1.0), (64, 32, 1.0, 0.5), (32, 256, 2.0, 1.0), (1024, 1024, 1.0, 1.0),
+                                   (2048, 16, 1.0, 1.0), (16, 2048, 1.0, 1.0)])
 def test_spectral_solve_matches_operator(V, O2, shape):
-    """MFMA f64 GEMM + DCT-I tables: (c0 + M(c1 + c2 M)) z == v for z = spectral_solve(v)."""
+    """Both DCT back ends (MFMA f64 GEMM for general grids, in-LDS FFT of every image size for
+    power-of-two grids): (c0 + M(c1 + c2 M)) z == v for z = spectral_solve(v)."""
     Nx, Ny, Lx, Ly = shape
     e = V.Engine2D(Nx=Nx, Ny=Ny, Lx=Lx, Ly=Ly, batch=2)
+    pow2 = lambda n: n >= 16 and n & (n - 1) == 0
+    assert e.uses_fft == (pow2(Nx) and pow2(Ny))
     rng = np.random.default_rng(3)
     v = rng.standard_normal((2, Nx + 1, Ny + 1))
     c0, c1, c2 = 7.0, 0.9, 3e-3
     z = e.spectral_solve(c0, c1, c2, v)
     hx, hy = Lx / Nx, Ly / Ny
+    mmax = 4.0 / hx ** 2 + 4.0 / hy ** 2
+    cond = (c0 + mmax * (c1 + c2 * mmax)) / c0            # the forward check amplifies round-off by cond
+    tol = max(1e-10, 200 * np.finfo(float).eps * cond)
     for b in range(2):
         M = lambda a: -O2.lap(a, hx, hy)
         chk = c0 * z[b] + M(c1 * z[b] + c2 * M(z[b]))
-        assert relerr(chk, v[b]) < 1e-10, (shape, b, relerr(chk, v[b]))
+        assert relerr(chk, v[b]) < tol, (shape, b, relerr(chk, v[b]), tol)
+    # and against the dense eigen-decomposition route on a smooth field (well-conditioned check)
+    xs, ys = np.linspace(0, Lx, Nx + 1), np.linspace(0, Ly, Ny + 1)
+    if Nx == Ny and hx == hy:
+        k, l = 3, 2
+        f = np.cos(k * np.pi * xs / Lx)[:, None] * np.cos(l * np.pi * ys / Ly)[None, :]      # eigenfunction of M
+        m = (2 - 2 * np.cos(k * np.pi / Nx)) / hx ** 2 + (2 - 2 * np.cos(l * np.pi / Ny)) / hy ** 2
+        zf = e.spectral_solve(c0, c1, c2, np.stack([f, 2 * f]))
+        assert relerr(zf[0], f / (c0 + m * (c1 + c2 * m))) < 1e-11
 
 
 @pytest.mark.parametrize("tag", ["16", "12x9"])
@@ -338,3 +354,25 @@ def test_size_independent_properties_256(V, O2):
     assert relerr(top, a) < 1e-9 and relerr(bot, b_) < 1e-9, st
     p, st = e.adjoint_solve(phi, dt, a)
     assert relerr(e.adjoint_apply("A", phi, dt, p), a) < 1e-9, st
+
+
+def test_solves_on_other_fft_sizes(V, O2):
+    """Newton-system and adjoint solves on grids that use the other FFT instantiations
+    (128^2 default grid: run-time length; 1024^2: 2048-point image; 64x32: non-square)."""
+    rng = np.random.default_rng(9)
+    for (Nx, Ny, Ly) in ((128, 128, 1.0), (64, 32, 0.5), (1024, 1024, 1.0)):
+        e = V.Engine2D(Nx=Nx, Ny=Ny, Ly=Ly, batch=1, max_steps=2)
+        shp = (Nx + 1, Ny + 1)
+        phi = rng.uniform(-0.7, 0.7, shp)
+        xs, ys = np.linspace(0, 1, Nx + 1), np.linspace(0, 1, Ny + 1)
+        a = np.cos(3 * np.pi * xs)[:, None] * np.cos(2 * np.pi * ys)[None, :] + 0.1 * rng.standard_normal(shp)
+        b_ = np.cos(np.pi * xs)[:, None] * np.ones(Ny + 1)[None, :] + 0.1 * rng.standard_normal(shp)
+        dt = 1e-3
+        dphi, dmu, st = e.jacobian_solve(phi, dt, a, b_)
+        top, bot = e.jacobian_apply(phi, dt, dphi, dmu)
+        tol = 1e-8 if Nx <= 128 else 1e-5       # the forward check amplifies round-off by cond(A) ~ N^4
+        assert relerr(top, a) < tol and relerr(bot, b_) < tol, (Nx, Ny, st)
+        assert st["max_lin_relres"] < 1e-14
+        p, st = e.adjoint_solve(phi, dt, a)
+        assert relerr(e.adjoint_apply("A", phi, dt, p), a) < tol, (Nx, Ny, st)
+        e.close()
