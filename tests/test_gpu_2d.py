@@ -376,3 +376,26 @@ def test_solves_on_other_fft_sizes(V, O2):
         p, st = e.adjoint_solve(phi, dt, a)
         assert relerr(e.adjoint_apply("A", phi, dt, p), a) < tol, (Nx, Ny, st)
         e.close()
+
+
+def test_pgd_eight_iterations_vs_oracle(V, O2):
+    """8 PGD iterations at 32^2 (alpha growth x1.2 capped at alpha_max, backtracking when it
+    overshoots) against the CPU oracle run here on the same inputs; batch of 2 seeds."""
+    N, T, dt = 32, 0.05, 1e-2
+    P = O2.Params2D(Nx=N, Ny=N, T=T, dt_initial=dt)
+    Op = O2.OptParams(alpha_max=200.0)
+    t, dts = V.time_grid(T, dt)
+    e = V.Engine2D(Nx=N, Ny=N, batch=2, max_steps=len(dts))
+    seeds = (42, 43)
+    phi0 = np.stack([O2.init_phi_random(N, N, 1e-2, amp=0.1, seed=s) for s in seeds])
+    refs = [O2.pgd(P, Op, n_iter=8, seed=s) for s in seeds]
+    J0 = e.pgd_init(phi0, np.stack([r.phi_T for r in refs]), t, V.make_opt(Op), ramp=True, T=T)
+    out = e.pgd_iterate(8)
+    u = e.pgd_get("u")
+    for b, r in enumerate(refs):
+        assert abs(J0[b, 4] / r.costs[0] - 1) < 1e-10
+        assert np.allclose(out["cost"][b], r.costs[1:], rtol=1e-7), (out["cost"][b], r.costs)
+        assert np.allclose(out["alpha"][b], r.alphas, rtol=1e-12), (out["alpha"][b], r.alphas)
+        assert list(out["attempts"][b]) == list(r.attempts)
+        assert relerr(u[b], r.u) < 1e-6
+    assert np.all(np.diff(np.concatenate([J0[:, 4:5], out["cost"]], axis=1), axis=1) < 0)      # monotone descent
