@@ -42,6 +42,7 @@ struct vch2d_ctx {
     double *wts_mass, *W_cost;            // single planes
     double *part;                         // [B][nblk][NPART]
     TrajState *st, *st_host;
+    int *frozen_dev;                      // [B] line-search flags for k_set_frozen
     double *hist_dev, *hist_host;         // [B][HIST_CAP]
     // DCT-I matrices and eigenvalues
     double *Q1f, *Q2f, *Q1s, *Q2s, *mf, *ms;
@@ -243,6 +244,7 @@ extern "C" vch2d_ctx *vch2d_create(const vch2d_params *p, int batch, int max_ste
     if (dalloc(&c->alpha_dev, batch, c->stream) || dalloc(&c->J_dev, 5 * (size_t)batch, c->stream)) return fail("hipMalloc");
     if (hipMalloc((void **)&c->st, sizeof(TrajState) * batch) != hipSuccess) return fail("hipMalloc");
     hipMemsetAsync(c->st, 0, sizeof(TrajState) * batch, c->stream);
+    if (hipMalloc((void **)&c->frozen_dev, sizeof(int) * batch) != hipSuccess) return fail("hipMalloc");
     if (hipHostMalloc((void **)&c->st_host, sizeof(TrajState) * batch) != hipSuccess) return fail("hipHostMalloc");
     if (hipHostMalloc((void **)&c->hist_host, sizeof(double) * batch * HIST_CAP) != hipSuccess) return fail("hipHostMalloc");
     c->phi_hist = c->u_hist = c->u_trial = c->phi_trial = c->phiQ = c->r_hist = c->p_hist = c->q_hist = nullptr;
@@ -318,6 +320,7 @@ extern "C" void vch2d_destroy(vch2d_ctx *c) {
     for (double *q : all)
         if (q) hipFree(q);
     hipFree(c->st);
+    hipFree(c->frozen_dev);
     if (c->tw_f) hipFree(c->tw_f);
     if (c->tw_s) hipFree(c->tw_s);
     hipHostFree(c->st_host);
@@ -516,6 +519,14 @@ static void fill_stats(vch2d_ctx *c, vch_stats *s, float ms) {
 
 static int reset_counters(vch2d_ctx *c) {
     HIPCHK(hipMemsetAsync(c->st, 0, sizeof(TrajState) * c->B, c->stream));
+    return 0;
+}
+
+// Trajectories with flags[b] != 0 skip the following marches (their kernels exit at once) until
+// the next reset_counters().
+static int freeze(vch2d_ctx *c, const std::vector<int> &flags) {
+    HIPCHK(hipMemcpyAsync(c->frozen_dev, flags.data(), sizeof(int) * c->B, hipMemcpyHostToDevice, c->stream));
+    LAUNCH(k_set_frozen, dim3((c->B + 63) / 64), dim3(64), c->st, (const int *)c->frozen_dev, c->B);
     return 0;
 }
 
@@ -1168,6 +1179,8 @@ extern "C" int vch2d_pgd_iterate(vch2d_ctx *c, int n_iters, double *cost_out, do
             HIPCHK(hipEventRecord(e0, c->stream));
             HIPCHK(hipMemcpyAsync(c->phi_s, c->phi0, sizeof(double) * B * c->G.plane, hipMemcpyDeviceToDevice, c->stream));
             VCHCHK(reset_counters(c));
+            // a trajectory whose step is already accepted (or that has stopped) sits the trial out
+            if (std::any_of(accepted.begin(), accepted.end(), [](int a) { return a != 0; })) VCHCHK(freeze(c, accepted));
             VCHCHK(forward_core(c, c->u_trial, rows, c->dt.data(), M, c->phi_trial));
             HIPCHK(hipEventRecord(e1, c->stream));
             sec[round == 0 ? 2 : 4] += elapsed_s(c, e0, e1);
@@ -1218,6 +1231,7 @@ extern "C" int vch2d_pgd_iterate(vch2d_ctx *c, int n_iters, double *cost_out, do
             }
             if (!pending) break;
         }
+        VCHCHK(reset_counters(c));
         done_iters = it + 1;
     }
     HIPCHK(hipMemcpyAsync(c->J_dev, c->pgd_J.data(), sizeof(double) * 5 * B, hipMemcpyHostToDevice, c->stream));

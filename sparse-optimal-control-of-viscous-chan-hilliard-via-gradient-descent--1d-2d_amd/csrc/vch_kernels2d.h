@@ -25,7 +25,7 @@ struct TrajState {
     int nsolves;         // linear solves started
     int ntrials;         // Armijo residual evaluations
     int stuck;           // 12 trials failed and no trial improved: state can never change again
-    int pad0;
+    int frozen;          // trajectory sits this march out (its line search has already accepted, G2:128-146)
     double normR;        // ||[R_phi;R_mu]||_2 of the current iterate
     double alpha;        // step of the pending trial
     double best_norm, best_alpha;
@@ -216,6 +216,7 @@ __global__ __launch_bounds__(NTH) void k_prepare(Geom G, Phys P, const TrajState
     __shared__ double sp[(TY + 2) * (TX + 2)];
     __shared__ double sm[(TY + 2) * (TX + 2)];
     constexpr int W = TX + 2;
+    if (st[b].frozen) return;
     const int slot = st[b].slot;
     load_tile<1>(sp, phi_s + slot * slot_stride + b * G.plane, G, c0, r0);
     load_tile<1>(sm, mu_s + slot * slot_stride + b * G.plane, G, c0, r0);
@@ -479,6 +480,7 @@ __global__ __launch_bounds__(NTH) void k_mass(Geom G, const TrajState *__restric
                                               int do_clip, double *__restrict__ part) {
     TILE_COORDS;
     __shared__ double sred[NPART * 4];
+    if (st[b].frozen) return;
     const int slot = st[b].slot;
     const double hi = 1.0 - DELTA_SEP;
     double acc[2] = {0.0, 0.0};
@@ -502,6 +504,7 @@ __global__ __launch_bounds__(NTH) void k_post(Geom G, Phys P, const TrajState *_
                                               long hist_stride) {
     TILE_COORDS;
     const TrajState S = st[b];
+    if (S.frozen) return;
     const double hi = 1.0 - DELTA_SEP;
     const bool fix = fabs(S.mass_err) > 1e-16;
     const bool interior_ok = S.Wint > 0.0;
@@ -789,10 +792,20 @@ constexpr int NEWTON_MAXIT = 500;      // F2:353
 constexpr double ARMIJO_ETA = 1e-4;    // F2:394
 constexpr int ARMIJO_TRIALS = 12;      // F2:398
 
+// Mark the trajectories that skip the coming march (flags[b] != 0).
+__global__ void k_set_frozen(TrajState *st, const int *__restrict__ flags, int B) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) st[b].frozen = flags[b];
+}
+
 // Start of a Newton call: arm the initial residual evaluation.
 __global__ void k_fin_newton_begin(TrajState *st) {
     TrajState &S = st[blockIdx.x];
     if (threadIdx.x != 0) return;
+    if (S.frozen) {
+        S.newton_active = S.need_trial = S.lin_active = 0;
+        return;
+    }
     S.newton_active = 1;
     S.need_trial = 1;
     S.trial_no = 0;
@@ -990,6 +1003,7 @@ __global__ void k_fin_ceiling(TrajState *st, const double *__restrict__ part, in
 __global__ void k_fin_mass(TrajState *st, const double *__restrict__ part, int nblk, int init) {
     const int b = blockIdx.x;
     TrajState &S = st[b];
+    if (S.frozen) return;
     double v[NPART];
     const int op[NPART] = {0, 0, 0, 0, 0, 0};
     fin_reduce(part, nblk, b, v, op, 2);

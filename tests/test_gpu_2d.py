@@ -314,6 +314,32 @@ def test_pgd_batch_matches_single(V, O2):
         assert relerr(u3[b], e1.pgd_get("u")) < 1e-10
 
 
+def test_pgd_batch_uneven_line_search(V, O2):
+    """Trajectories whose line searches end after different numbers of trials (the accepted ones sit
+    the remaining trial marches out): every trajectory still reproduces its single-trajectory run."""
+    N, T, dt = 16, 0.1, 1e-2
+    t, dts = V.time_grid(T, dt)
+    M = len(dts)
+    xs = np.linspace(0, 1, N + 1)
+    base = np.sin(2 * np.pi * xs)[:, None] * np.cos(np.pi * xs)[None, :]
+    amps = [0.7, 0.3, 0.02, 0.95]
+    phi_T = np.stack([a * base for a in amps])
+    phi0 = np.stack([O2.init_phi_random(N, N, 1e-2, amp=0.1, seed=7 + i) for i in range(4)])
+    opt = V.make_opt(alpha_max=4.0e4)     # overshooting optimistic step, as in the reference-made g2d_pgd_16_bt
+    e4 = V.Engine2D(Nx=N, Ny=N, batch=4, max_steps=M)
+    e4.pgd_init(phi0, phi_T, t, opt, ramp=True, T=T)
+    r4 = e4.pgd_iterate(4)
+    u4, p4 = e4.pgd_get("u"), e4.pgd_get("phi")
+    assert len({tuple(a) for a in r4["attempts"]}) > 1, r4["attempts"]      # the searches really differ
+    e1 = V.Engine2D(Nx=N, Ny=N, batch=1, max_steps=M)
+    for b in range(4):
+        e1.pgd_init(phi0[b], phi_T[b], t, opt, ramp=True, T=T)
+        r1 = e1.pgd_iterate(4)
+        assert np.array_equal(r4["attempts"][b], r1["attempts"][0])
+        assert np.allclose(r4["cost"][b], r1["cost"][0], rtol=1e-12)
+        assert relerr(u4[b], e1.pgd_get("u")) < 1e-10 and relerr(p4[b], e1.pgd_get("phi")) < 1e-10
+
+
 # ---------------------------------------------------------------------------------------
 # full-size checks
 # ---------------------------------------------------------------------------------------
