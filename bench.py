@@ -183,7 +183,7 @@ def main():
         prof = eng.prof_end()
         nodes = (N + 1) * (N + 1) * Bc
         alg = {  # algorithmic bytes / flops per launch
-            "schur_p": ("hbm", 40.0 * nodes), "adj_q": ("hbm", 32.0 * nodes), "residual": ("hbm", 88.0 * nodes),
+            "schur_p": ("hbm", 72.0 * nodes), "adj_q": ("hbm", 32.0 * nodes), "residual": ("hbm", 88.0 * nodes),
             "cg_update": ("hbm", 48.0 * nodes), "adj_rhs": ("hbm", 72.0 * nodes),
             # DCT preconditioner: three FFT passes (field in, field out) or four MFMA f64 GEMMs
             "dct": ("hbm", 16.0 * nodes) if eng.uses_fft else ("mfma", 2.0 * (N + 1) ** 3 * Bc),

@@ -36,6 +36,8 @@ struct vch2d_ctx {
     // work planes [B][plane]
     double *w, *wnew, *mu0, *cphi, *cmu, *x, *r, *dmu, *t1, *t2;
     double *cg_p[2], *cg_v, *cg_q;        // CG search directions / operator images
+    double *cg_z2;                        // second residual buffer of the forward CG (z ping-pongs r <-> cg_z2)
+    double *gpart2;                       // second half of gpart
     double *gpart;                        // [B][gnblk] partials written by the GEMM epilogue
     int gnblk;
     double *tmp[6];
@@ -233,13 +235,14 @@ extern "C" vch2d_ctx *vch2d_create(const vch2d_params *p, int batch, int max_ste
     for (auto q : two)
         if (dalloc(q, 2 * bp, c->stream)) return fail("hipMalloc");
     double **one[] = {&c->w, &c->wnew, &c->mu0, &c->cphi, &c->cmu, &c->x, &c->r, &c->dmu, &c->t1, &c->t2,
-                      &c->cg_p[0], &c->cg_p[1], &c->cg_v, &c->cg_q, &c->tmp[0], &c->tmp[1], &c->tmp[2], &c->tmp[3], &c->tmp[4], &c->tmp[5], &c->phiT, &c->phi0};
+                      &c->cg_p[0], &c->cg_p[1], &c->cg_v, &c->cg_q, &c->cg_z2, &c->tmp[0], &c->tmp[1], &c->tmp[2], &c->tmp[3], &c->tmp[4], &c->tmp[5], &c->phiT, &c->phi0};
     for (auto q : one)
         if (dalloc(q, bp, c->stream)) return fail("hipMalloc");
     if (dalloc(&c->wts_mass, G.plane, c->stream) || dalloc(&c->W_cost, G.plane, c->stream)) return fail("hipMalloc");
     if (dalloc(&c->part, (size_t)batch * c->nblk * NPART, c->stream)) return fail("hipMalloc");
     c->gnblk = ((G.nf + GN - 1) / GN) * ((G.ns + GM - 1) / GM);
-    if (dalloc(&c->gpart, (size_t)batch * (c->gnblk + G.ns), c->stream)) return fail("hipMalloc");
+    if (dalloc(&c->gpart, 2 * (size_t)batch * (c->gnblk + G.ns), c->stream)) return fail("hipMalloc");
+    c->gpart2 = c->gpart + (size_t)batch * (c->gnblk + G.ns);
     if (dalloc(&c->hist_dev, (size_t)batch * HIST_CAP, c->stream)) return fail("hipMalloc");
     if (dalloc(&c->alpha_dev, batch, c->stream) || dalloc(&c->J_dev, 5 * (size_t)batch, c->stream)) return fail("hipMalloc");
     if (hipMalloc((void **)&c->st, sizeof(TrajState) * batch) != hipSuccess) return fail("hipMalloc");
@@ -313,7 +316,7 @@ extern "C" void vch2d_destroy(vch2d_ctx *c) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     double *all[] = {c->phi_s, c->mu_s, c->Rphi_s, c->rhs_s, c->D_s, c->w, c->wnew, c->mu0, c->cphi, c->cmu, c->x,
-                     c->r, c->dmu, c->t1, c->t2, c->cg_p[0], c->cg_p[1], c->cg_v, c->cg_q, c->gpart, c->tmp[0], c->tmp[1], c->tmp[2], c->tmp[3], c->tmp[4], c->tmp[5],
+                     c->r, c->dmu, c->t1, c->t2, c->cg_p[0], c->cg_p[1], c->cg_v, c->cg_q, c->cg_z2, c->gpart, c->tmp[0], c->tmp[1], c->tmp[2], c->tmp[3], c->tmp[4], c->tmp[5],
                      c->phiT, c->phi0, c->wts_mass, c->W_cost, c->part, c->hist_dev, c->alpha_dev, c->J_dev, c->Q1f,
                      c->Q2f, c->Q1s, c->Q2s, c->mf, c->ms, c->phi_hist, c->u_hist, c->u_trial, c->phi_trial, c->phiQ,
                      c->r_hist, c->p_hist, c->q_hist, c->cost_part, c->cost_lvl, c->tfrac_dev};
@@ -355,7 +358,7 @@ static int precond(vch2d_ctx *c, const double *in, long in_slot_stride, double *
     const Geom &G = c->G;
     const int ns = G.ns, nf = G.nf;
     dim3 g((nf + GN - 1) / GN, (ns + GM - 1) / GM, c->B);
-    SpecArgs sp{c0, c1a, c1b, c2, c->ms, c->mf, other, c->D_s, c->slot_stride, c->gpart};
+    SpecArgs sp{c0, c1a, c1b, c2, c->ms, c->mf, other, c->D_s, c->slot_stride, c->gpart, c->gpart2};
     if (c->use_fft) {
         const double scale = 1.0 / (4.0 * (double)c->fax.N * (double)c->sax.N);
         // C = complex doubles per workgroup: 1024 (one wavefront) unless the FFT is longer
@@ -433,33 +436,32 @@ static int schur_solve(vch2d_ctx *c, double dt, int budget) {
     if (budget <= 0) return 0;
     const double c0 = 1.0 / dt, c2 = 0.5 * c->P.kappa;
     HIPCHK(hipMemsetAsync(c->x, 0, sizeof(double) * c->B * c->G.plane, c->stream));
-    double *z = c->r;
-    VCHCHK(precond(c, c->rhs_s, c->slot_stride, z, 3, nullptr, c0, 0.0, 1.0, c2, 1));      // z = P^-1 rhs, <z,z>_Z
+    double *zb[2] = {c->r, c->cg_z2};               // z_k lives in zb[k & 1]
+    VCHCHK(precond(c, c->rhs_s, c->slot_stride, zb[0], 3, nullptr, c0, 0.0, 1.0, c2, 1));      // z = P^-1 rhs, <z,z>_Z
     LAUNCH(k_fin_cg_init, dim3(c->B), dim3(64), c->st, c->gpart, c->gnblk);
     int done = 0;
     while (done < budget) {
         const int chunk = std::min(budget - done, CG_CHUNK);
         for (int j = 0; j < chunk; ++j, ++done) {
             double *pn = c->cg_p[done & 1], *po = c->cg_p[(done + 1) & 1];
+            // the step of iteration done-1 goes into x and z on the way (see k_schur_p)
             if (done == 0) {
-                LAUNCHC(PC_SCHUR_P, (k_schur_p<1>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, z, po, c->D_s, dt, pn, c->cg_v);
+                LAUNCHC(PC_SCHUR_P, (k_schur_p<1>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, zb[0], c->cg_q, po, c->D_s, dt,
+                        c->x, zb[1], pn, c->cg_v, c->part);
             } else {
-                LAUNCHC(PC_SCHUR_P, (k_schur_p<0>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, z, po, c->D_s, dt, pn, c->cg_v);
+                LAUNCHC(PC_SCHUR_P, (k_schur_p<0>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, zb[(done + 1) & 1], c->cg_q, po,
+                        c->D_s, dt, c->x, zb[done & 1], pn, c->cg_v, c->part);
             }
-            VCHCHK(precond(c, c->cg_v, 0, c->cg_q, 3, pn, c0, 0.0, 1.0, c2, 1));           // q = P^-1 A p, <p,q>_Z
-            LAUNCH(k_fin_cg_alpha, dim3(c->B), dim3(64), c->st, c->gpart, c->gnblk, 1, 0);
-            if (done == 0) {
-                LAUNCHC(PC_CG_UPDATE, (k_cg_update<1>), c->grid, dim3(NTH), c->G, c->st, c->slot_stride, pn, c->cg_q, c->D_s, c->x, z, c->part);
-            } else {
-                LAUNCHC(PC_CG_UPDATE, (k_cg_update<0>), c->grid, dim3(NTH), c->G, c->st, c->slot_stride, pn, c->cg_q, c->D_s, c->x, z, c->part);
-            }
-            LAUNCH(k_fin_cg_beta, dim3(c->B), dim3(64), c->st, c->part, c->nblk, 0, c->lin_tol, c->lin_maxit, 0);
+            VCHCHK(precond(c, c->cg_v, 0, c->cg_q, 3, pn, c0, 0.0, 1.0, c2, 1));           // q = P^-1 A p, <p,q>_Z, <q,q>_Z
+            LAUNCH(k_fin_cg_step, dim3(c->B), dim3(64), c->st, c->gpart, c->gpart2, c->gnblk, c->part, c->nblk, done > 0 ? 1 : 0,
+                   done & 1, c->lin_tol, c->lin_maxit);
         }
         if (done < budget) {
             VCHCHK(sync_state(c));
             if (!any_lin_active(c)) break;
         }
     }
+    LAUNCHC(PC_CG_UPDATE, k_cg_finish, c->grid, dim3(NTH), c->G, c->st, c->cg_p[0], c->cg_p[1], c->x);
     return 0;
 }
 

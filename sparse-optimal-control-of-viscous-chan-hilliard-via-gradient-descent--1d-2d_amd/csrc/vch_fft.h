@@ -155,8 +155,9 @@ __device__ __forceinline__ void fft_lds(double2 *buf, const FftAxis ax) {
     }
 }
 
-// E along the fast axis.  EPI 0: out = scale * E(in);  EPI 3: same + per-workgroup partial of
-// sum W (D[slot] - dbar) (other ? other : out) * out  into sp.gpart[b * gridDim.x + blockIdx.x].
+// E along the fast axis.  EPI 0: out = scale * E(in);  EPI 3: same + per-workgroup partials of
+// sum W (D[slot] - dbar) (other ? other : out) * out  into sp.gpart[b * gridDim.x + blockIdx.x] and of
+// sum W (D[slot] - dbar) out * out into sp.gpart2[same].
 template <int EPI, int C, int LOGL>
 __global__ __launch_bounds__(FftThreads<C>::T) void k_dct_rows(Geom G, FftAxis ax, const double *__restrict__ in,
                                                   long in_slot_stride, double *__restrict__ out, double scale,
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(FftThreads<C>::T) void k_dct_rows(Geom G, FftAxis a
     }
     __syncthreads();
     fft_lds<C, LOGL>(buf, ax);
-    double dot = 0.0, dbar = 0.0;
+    double dot = 0.0, dot2 = 0.0, dbar = 0.0;
     const double *Dp = nullptr, *Ob = nullptr;
     if (EPI == 3) {
         dbar = st[b].dbar;
@@ -197,19 +198,31 @@ __global__ __launch_bounds__(FftThreads<C>::T) void k_dct_rows(Geom G, FftAxis a
             const double v = scale * ((rr & 1) ? c.y : c.x);
             const long o = (long)row * G.pitch + k;
             ob[o] = v;
-            if (EPI == 3) dot += wdev(row, k, G) * (Dp[o] - dbar) * ((Ob ? Ob[o] : v) * v);
+            if (EPI == 3) {
+                const double wd = wdev(row, k, G) * (Dp[o] - dbar);
+                dot += wd * ((Ob ? Ob[o] : v) * v);
+                dot2 += wd * (v * v);
+            }
         }
     }
     if (EPI == 3) {
         dot = wave_sum(dot);
+        dot2 = wave_sum(dot2);
         __syncthreads();
         double *sred = reinterpret_cast<double *>(buf);
-        if ((tid & 63) == 0) sred[tid >> 6] = dot;
+        if ((tid & 63) == 0) {
+            sred[tid >> 6] = dot;
+            sred[T / 64 + (tid >> 6)] = dot2;
+        }
         __syncthreads();
         if (tid == 0) {
-            double tot = 0.0;
-            for (int w = 0; w < T / 64; ++w) tot += sred[w];
+            double tot = 0.0, tot2 = 0.0;
+            for (int w = 0; w < T / 64; ++w) {
+                tot += sred[w];
+                tot2 += sred[T / 64 + w];
+            }
             sp.gpart[(long)b * gridDim.x + blockIdx.x] = tot;
+            sp.gpart2[(long)b * gridDim.x + blockIdx.x] = tot2;
         }
     }
 }

@@ -35,6 +35,7 @@ struct SpecArgs {           // multiplier = 1 / (c0 + m (c1a + c1b*dbar[b] + c2 
     const double *Dslot;     // slot-indexed D planes
     long d_slot_stride;
     double *gpart;           // [B][gridDim.x*gridDim.y]
+    double *gpart2;          // same layout: partial of sum W (D - dbar) C * C
 };
 
 // EPI: 0 store, 1 store * spectral multiplier, 2 accumulate (C += A B), 3 store + weighted dot partial
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(256) void k_gemm(int M, int N, int K, const double 
         __syncthreads();
     }
     double *Cb = C + b * sC;
-    double c1 = 0.0, dot = 0.0, dbar = 0.0;
+    double c1 = 0.0, dot = 0.0, dot2 = 0.0, dbar = 0.0;
     const double *Dp = nullptr, *Ob = nullptr;
     if (EPI == 1) c1 = sp.c1a + sp.c1b * st[b].dbar;
     if (EPI == 3) {
@@ -132,18 +133,26 @@ __global__ __launch_bounds__(256) void k_gemm(int M, int N, int K, const double 
                         v += Cb[o];
                     } else if (EPI == 3) {
                         double wgt = ((row == 0 || row == M - 1) ? 0.5 : 1.0) * ((col == 0 || col == N - 1) ? 0.5 : 1.0);
-                        dot += wgt * (Dp[o] - dbar) * ((Ob ? Ob[o] : v) * v);
+                        const double wd = wgt * (Dp[o] - dbar);
+                        dot += wd * ((Ob ? Ob[o] : v) * v);
+                        dot2 += wd * (v * v);
                     }
                     Cb[o] = v;
                 }
             }
     if (EPI == 3) {
         dot = wave_sum(dot);
+        dot2 = wave_sum(dot2);
         __syncthreads();
-        if (lane == 0) As[wv] = dot;
+        if (lane == 0) {
+            As[wv] = dot;
+            As[4 + wv] = dot2;
+        }
         __syncthreads();
-        if (tid == 0)
-            sp.gpart[(long)b * (gridDim.x * gridDim.y) + blockIdx.y * gridDim.x + blockIdx.x] =
-                (As[0] + As[1]) + (As[2] + As[3]);
+        if (tid == 0) {
+            const long go = (long)b * (gridDim.x * gridDim.y) + blockIdx.y * gridDim.x + blockIdx.x;
+            sp.gpart[go] = (As[0] + As[1]) + (As[2] + As[3]);
+            sp.gpart2[go] = (As[4] + As[5]) + (As[6] + As[7]);
+        }
     }
 }

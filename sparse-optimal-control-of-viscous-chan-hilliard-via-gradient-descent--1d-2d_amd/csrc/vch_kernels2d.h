@@ -38,7 +38,8 @@ struct TrajState {
     double lin_r0, lin_prev, lin_rel, lin_maxrel;
     // conjugate gradients in the weighted inner product (see k_schur_p)
     double cg_gamma, cg_gamma0, cg_alpha, cg_beta;
-    int lin_budget, cg_pad;    // rigorous iteration bound from the spectrum of P^-1 A
+    int lin_budget;            // rigorous iteration bound from the spectrum of P^-1 A
+    int cg_pending, cg_pbuf, cg_pad;   // forward CG: step (alpha, p[cg_pbuf]) computed but not yet added to x
     // mass fix (F2:565-577)
     double mass0, mass_err, Wint;
     // scratch for cost / change norms
@@ -922,6 +923,7 @@ __device__ __forceinline__ double fin_sum1(const double *part, int n, int b, int
 __global__ void k_fin_cg_init(TrajState *st, const double *__restrict__ gpart, int gnblk) {
     const int b = blockIdx.x;
     TrajState &S = st[b];
+    if (threadIdx.x == 0) S.cg_pending = 0;
     if (!S.lin_active) return;
     double g = fin_sum1(gpart, gnblk, b, 1, 0);
     if (threadIdx.x != 0) return;
@@ -930,6 +932,51 @@ __global__ void k_fin_cg_init(TrajState *st, const double *__restrict__ gpart, i
     S.lin_it = 0;
     S.lin_rel = 1.0;
     if (!(g > 0.0)) S.lin_active = 0;        // zero right-hand side: x = 0 is the solution
+}
+
+// Forward CG, the one reduction point of an iteration (see the header of the CG section).
+//   gpart / gpart2: partials of <p,q>_Z and <q,q>_Z from the preconditioner epilogue;
+//   part[.,0]: partial of <z,z>_Z from k_schur_p (direct != 0), else gamma is the stored one.
+__global__ void k_fin_cg_step(TrajState *st, const double *__restrict__ gpart, const double *__restrict__ gpart2,
+                              int gnblk, const double *__restrict__ part, int nblk, int direct, int pbuf,
+                              double tol, int maxit) {
+    const int b = blockIdx.x;
+    TrajState &S = st[b];
+    if (!S.lin_active) return;
+    const double pq = fin_sum1(gpart, gnblk, b, 1, 0);
+    const double qq = fin_sum1(gpart2, gnblk, b, 1, 0);
+    const double gd = direct ? fin_sum1(part, nblk, b, NPART, 0) : 0.0;
+    if (threadIdx.x != 0) return;
+    const double gamma = direct ? gd : S.cg_gamma;
+    S.cg_pending = 0;                        // the previous step went into x in k_schur_p
+    if (!(pq > 0.0) || !(gamma > 0.0)) {     // round-off level residual: stop here
+        S.lin_active = 0;
+        S.cg_alpha = 0.0;
+        S.lin_rel = S.cg_gamma0 > 0.0 ? sqrt(fmax(gamma, 0.0) / S.cg_gamma0) : 0.0;
+        if (S.lin_rel > S.lin_maxrel) S.lin_maxrel = S.lin_rel;
+        return;
+    }
+    const double alpha = gamma / pq;
+    double gn = alpha * alpha * qq - gamma;
+    double beta;
+    if (gn > 1e-13 * gamma) {
+        beta = gn / gamma;
+    } else {                                  // prediction lost in cancellation: restart the direction
+        gn = 1e-13 * gamma;
+        beta = 0.0;
+    }
+    S.cg_alpha = alpha;
+    S.cg_beta = beta;
+    S.cg_gamma = gn;
+    S.cg_pending = 1;
+    S.cg_pbuf = pbuf;
+    S.lin_it++;
+    S.lin_total++;
+    S.lin_rel = sqrt(gn / S.cg_gamma0);
+    if (!(S.lin_rel > tol) || S.lin_it >= maxit) {
+        S.lin_active = 0;
+        if (S.lin_rel > S.lin_maxrel) S.lin_maxrel = S.lin_rel;
+    }
 }
 
 // alpha = gamma / <p, q>_Z ; src 0: GEMM partials (1 value), src 1: stencil partials (slot k)
@@ -1152,29 +1199,49 @@ __global__ __launch_bounds__(NTH) void k_ramp(Geom G, int tiles_f, const double 
 //
 // Forward (left preconditioning):  T = P^-1 A,  A = I/dt + M (kappa/2 M + D) = P + M Delta,
 //   Delta = D - dbar > 0.  T is self-adjoint and positive in <x, y>_Z = sum W Delta x y, so
-//   plain CG applies with z = P^-1 (rhs - A x) as residual:
-//       v = A p; q = P^-1 v; alpha = <z,z>_Z / <p,q>_Z; x += alpha p; z -= alpha q;
-//       beta = <z',z'>_Z / <z,z>_Z; p = z' + beta p.
+//   plain CG applies with z = P^-1 (rhs - A x) as residual.  One reduction point per iteration:
+//       [k_schur_p]   x += alpha p; z' = z - alpha q; p' = z' + beta p; v = A p'; gamma = <z',z'>_Z
+//       [3 DCT passes] q' = P^-1 v with <p',q'>_Z and <q',q'>_Z
+//       [k_fin_cg_step] alpha' = gamma / <p',q'>;  gamma' ~ alpha'^2 <q',q'> - gamma  (the value
+//                     <z'',z''>_Z will take, by conjugacy);  beta' = gamma'/gamma;  stop test on gamma'
+//   gamma itself is always the directly summed <z',z'>_Z of the previous line; the predicted
+//   gamma' only steers beta and the stop test, and a prediction lost in cancellation
+//   (gamma' < 1e-13 gamma) restarts the direction (beta = 0) instead.
 // Adjoint (right preconditioning): A P^-1 is self-adjoint in <x, y>_Z' = sum W x y / Delta:
 //       pv = P^-1 ph; q = A pv; alpha = <r,r>_Z' / <ph,q>_Z'; x += alpha pv; r -= alpha q;
 //       beta = <r',r'>_Z' / <r,r>_Z'; ph = r' + beta ph.
 // =================================================================================
 
-// p_new = z + beta p_old (recomputed on the halo), v = A p_new.  FIRST: p_new = z.
+// FIRST: p_new = z, v = A p_new.  Otherwise the pending step is applied on the way:
+//   x += alpha p_old; z_new = z - alpha q; p_new = z_new + beta p_old (z_new and p_new recomputed on
+//   the halo, z_new written to its own buffer so that neighbours still read z), v = A p_new, and the
+//   partial of <z_new, z_new>_Z goes to part[.,0].
 template <int FIRST>
 __global__ __launch_bounds__(NTH) void k_schur_p(Geom G, Phys P, const TrajState *__restrict__ st,
                                                  long slot_stride, const double *__restrict__ z,
-                                                 const double *__restrict__ p_old, const double *__restrict__ D_s,
-                                                 double dt, double *__restrict__ p_new, double *__restrict__ v) {
+                                                 const double *__restrict__ q, const double *__restrict__ p_old,
+                                                 const double *__restrict__ D_s, double dt,
+                                                 double *__restrict__ x, double *__restrict__ z_new,
+                                                 double *__restrict__ p_new, double *__restrict__ v,
+                                                 double *__restrict__ part) {
     TILE_COORDS;
     const TrajState S = st[b];
     if (!S.lin_active) return;
     __shared__ double sx[(TY + 4) * (TX + 4)];
     __shared__ double stt[(TY + 2) * (TX + 2)];
+    __shared__ double sred[NPART * 4];
     constexpr int W2 = TX + 4, W1 = TX + 2;
     const long pb = b * G.plane;
-    if (FIRST) load_tile<2>(sx, z + pb, G, c0, r0);
-    else load_tile_axpy<2>(sx, z + pb, p_old + pb, S.cg_beta, G, c0, r0);
+    if (FIRST) {
+        load_tile<2>(sx, z + pb, G, c0, r0);
+    } else {
+        for (int e = threadIdx.x; e < W2 * (TY + 4); e += NTH) {
+            int ly = e / W2, lxx = e - ly * W2;
+            int gr = refl(r0 - 2 + ly, G.ns), gc = refl(c0 - 2 + lxx, G.nf);
+            long o = pb + (long)gr * G.pitch + gc;
+            sx[e] = (z[o] - S.cg_alpha * q[o]) + S.cg_beta * p_old[o];
+        }
+    }
     __syncthreads();
     const double *Dp = D_s + S.slot * slot_stride + pb;
     for (int e = threadIdx.x; e < (TY + 2) * W1; e += NTH) {
@@ -1185,43 +1252,44 @@ __global__ __launch_bounds__(NTH) void k_schur_p(Geom G, Phys P, const TrajState
     }
     __syncthreads();
     const double idt = 1.0 / dt;
+    double acc[1] = {0.0};
     for (int k = 0; k < TY / 4; ++k) {
         int ly = ly0 + 4 * k, r = r0 + ly, c = c0 + lx;
         if (r < G.ns && c < G.nf) {
             int p1 = (ly + 1) * W1 + lx + 1, p2 = (ly + 2) * W2 + lx + 2;
             long o = pb + (long)r * G.pitch + c;
+            if (!FIRST) {
+                double po = p_old[o];
+                double zn = z[o] - S.cg_alpha * q[o];
+                x[o] += S.cg_alpha * po;
+                z_new[o] = zn;
+                acc[0] += wdev(r, c, G) * (Dp[(long)r * G.pitch + c] - S.dbar) * (zn * zn);
+            }
             p_new[o] = sx[p2];
             v[o] = sx[p2] * idt - lap_at<W1>(stt, p1, G.ax, G.ay);
         }
     }
+    if (!FIRST) {
+        const int op[1] = {0};
+        block_reduce_store<1>(acc, op, sred, part + ((long)b * nblk + blk) * NPART);
+    }
 }
 
-// x (+)= alpha p; z -= alpha q; partial sum W (D - dbar) z^2.
-template <int FIRST>
-__global__ __launch_bounds__(NTH) void k_cg_update(Geom G, const TrajState *__restrict__ st, long slot_stride,
-                                                   const double *__restrict__ p, const double *__restrict__ q,
-                                                   const double *__restrict__ D_s, double *__restrict__ x,
-                                                   double *__restrict__ z, double *__restrict__ part) {
+// End of a forward CG solve: add the step that is still pending, x += alpha p[cg_pbuf].
+__global__ __launch_bounds__(NTH) void k_cg_finish(Geom G, const TrajState *__restrict__ st,
+                                                   const double *__restrict__ p0, const double *__restrict__ p1,
+                                                   double *__restrict__ x) {
     TILE_COORDS;
     const TrajState S = st[b];
-    if (!S.lin_active) return;
-    __shared__ double sred[NPART * 4];
-    const long pb = b * G.plane;
-    double acc[1] = {0.0};
+    if (!S.cg_pending) return;
+    const double *p = S.cg_pbuf ? p1 : p0;
     for (int k = 0; k < TY / 4; ++k) {
         int r = r0 + ly0 + 4 * k, c = c0 + lx;
         if (r < G.ns && c < G.nf) {
-            long o = pb + (long)r * G.pitch + c;
-            double xn = S.cg_alpha * p[o];
-            if (!FIRST) xn += x[o];
-            x[o] = xn;
-            double zn = z[o] - S.cg_alpha * q[o];
-            z[o] = zn;
-            acc[0] += wdev(r, c, G) * (D_s[S.slot * slot_stride + o] - S.dbar) * (zn * zn);
+            long o = b * G.plane + (long)r * G.pitch + c;
+            x[o] += S.cg_alpha * p[o];
         }
     }
-    const int op[1] = {0};
-    block_reduce_store<1>(acc, op, sred, part + ((long)b * nblk + blk) * NPART);
 }
 
 // ph = r + beta ph (FIRST: ph = r)
