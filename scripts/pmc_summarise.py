@@ -12,8 +12,9 @@ import csv, glob, json, sys, collections
 out = sys.argv[1]
 N, B, M = 512, 8, 40
 nodes = (N + 1) * (N + 1) * B
-alg = {"k_schur_p<0>": (24, 16), "k_cg_update<0>": (40, 16), "k_residual<1>": (48, 40), "k_dct_rows<0, 1024>": (8, 8),
-       "k_dct_cols<1024>": (8, 8), "k_adj_q": (24, 8), "k_grad_prox": (16, 8), "k_cost": (24, 0)}
+alg = {"k_schur_p<0>": (40, 32), "k_schur_p<1>": (16, 16), "k_residual<1>": (48, 40), "k_dct_rows<0, 1024, 10>": (8, 8),
+       "k_dct_rows<3, 1024, 10>": (24, 8), "k_dct_cols<1024, 10>": (8, 8), "k_adj_q": (24, 8), "k_cg_update_adj": (32, 16),
+       "k_grad_prox": (16, 8), "k_cost": (24, 0)}
 res = {}
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     files = glob.glob(f"{out}/{ctr}/*/*counter_collection.csv")

@@ -6,7 +6,7 @@ set -e
 cd /tmp && export TMPDIR=/tmp && cd ${GRAFT_REPO_ROOT:-/root/repo}
 OUT=gpurun_out/pmc
 rm -rf $OUT && mkdir -p $OUT
-ARGS="--steps 1 --warmup 0 --time-steps 40 --no-cpu-baseline --no-roofline"
+ARGS="--steps 1 --warmup 0 --time-steps 40 --contexts 1 --no-cpu-baseline --no-roofline"
 for CTR in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 400 rocprofv3 --pmc $CTR --kernel-trace --output-format csv -d $OUT/$CTR -- python bench.py $ARGS > $OUT/$CTR.json 2> $OUT/$CTR.err
 done

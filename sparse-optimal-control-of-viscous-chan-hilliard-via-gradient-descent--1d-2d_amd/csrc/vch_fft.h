@@ -33,14 +33,6 @@ struct FftAxis {
 };
 
 
-// XCD-aware bijective remap of a 1-D block index: workgroups are dealt round-robin over the 8
-// XCDs (blocks b and b+8 share an L2), so logically adjacent work items -- which here share
-// 128-byte lines -- are given to the SAME XCD in contiguous chunks.  Speed only, never correctness.
-__device__ __forceinline__ int xcd_remap(int bid, int n) {
-    const int q = n >> 3, r = n & 7, xcd = bid & 7, idx = bid >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-}
-
 __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
     return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }

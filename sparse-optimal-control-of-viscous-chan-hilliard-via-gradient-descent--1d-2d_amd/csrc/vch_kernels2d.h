@@ -149,12 +149,24 @@ __device__ __forceinline__ void block_reduce_store(double (&v)[N], const int (&o
     }
 }
 
+// XCD-aware bijective remap of a 1-D block index: workgroups are dealt round-robin over the 8
+// XCDs (blocks b and b+8 share an L2), so logically adjacent work items -- which here share
+// 128-byte lines -- are given to the SAME XCD in contiguous chunks.  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int bid, int n) {
+    const int q = n >> 3, r = n & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// Tile of a stencil workgroup: the workgroups of one plane that land on the same XCD (dispatch index
+// mod 8) are given a contiguous, column-major run of tiles, so vertically adjacent tiles -- whose 2-row
+// halos are a quarter of a 64 x 16 tile -- meet in one L2; every XCD still gets an equal share of
+// every trajectory.  blk doubles as the (bijective) index of the workgroup's reduction partial.
 #define TILE_COORDS                                   \
     const int b = blockIdx.z;                         \
-    const int c0 = blockIdx.x * TX, r0 = blockIdx.y * TY; \
-    const int lx = threadIdx.x & 63, ly0 = threadIdx.x >> 6; \
-    const int blk = blockIdx.y * gridDim.x + blockIdx.x;  \
     const int nblk = gridDim.x * gridDim.y;           \
+    const int blk = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, nblk); \
+    const int c0 = (blk / (int)gridDim.y) * TX, r0 = (blk % (int)gridDim.y) * TY; \
+    const int lx = threadIdx.x & 63, ly0 = threadIdx.x >> 6; \
     (void)blk; (void)nblk; (void)lx; (void)ly0
 
 // ---------------------------------------------------------------------------------
