@@ -193,13 +193,27 @@ def main():
         extra["kernel_time_ms"] = {k: round(v["ms"], 3) for k, v in prof.items()}
         extra["kernel_launches"] = {k: v["launches"] for k, v in prof.items()}
 
+        # HBM-side traffic per launch from the committed PMC passes (scripts/pmc_traffic.sh: separate
+        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this bench at B = 8 per launch, gfx950 read
+        # correction calibrated on k_grad_prox), scaled to this run's trajectories per launch
+        pmc = {}
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")) as fh:
+                pk = json.load(fh)["kernels"]
+            tr = lambda names: sum(pk[n]["fetch_corrected"] + pk[n]["write_raw"] for n in names) / len(names) * Bc / 8.0
+            pmc = {"dct": tr(["k_dct_rows<0, 1024, 10>", "k_dct_cols<1024, 10>", "k_dct_rows<3, 1024, 10>"]),
+                   "schur_p": tr(["k_schur_p<0>"]), "residual": tr(["k_residual<1>"]), "adj_q": tr(["k_adj_q"])}
+        except (OSError, KeyError, ValueError):
+            pmc = {}
+        use_pmc = (N == 512 and eng.uses_fft)
+
         def roof_of(k):
             kind, per = alg[k]
             avg_s = prof[k]["ms"] * 1e-3 / max(prof[k]["launches"], 1)
             if kind == "hbm":
                 ach = per / avg_s / 1e9
                 return dict(kernel=k, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
-                            frac=ach / HBM_PEAK_GBS, traffic=None, avg_us=avg_s * 1e6,
+                            frac=ach / HBM_PEAK_GBS, traffic=(pmc.get(k) if use_pmc else None), avg_us=avg_s * 1e6,
                             launches=prof[k]["launches"], algorithmic_bytes_per_launch=per)
             ach = per / avg_s / 1e12
             return dict(kernel=k, bound="mfma", achieved=ach, peak=FP64_MFMA_PEAK_TF, unit="TFLOP/s",
