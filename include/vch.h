@@ -250,6 +250,27 @@ int vch1d_cost(vch1d_ctx *ctx, const double *phi_hist, const double *u, const do
 int vch1d_grad_prox(vch1d_ctx *ctx, const double *u, const double *r, int rows, const double *alpha,
                     const vch_opt_params *opt, double *u_out);
 
+/* Device-resident PGD loop of the 1D driver (the __main__ block of GD_1D.py, G1:333-477, with
+ * perform_backtracking_line_search G1:73-113): control, state history, adjoint and targets stay in
+ * HBM between iterations.  rows = M+2 (duplicated t = 0 row), t_hist [rows], dt [M], x [N+1].
+ *   init: uncontrolled march from phi0 (G1:341), u = 0, targets phi_T [B][N+1] and phi_Q
+ *   [B][rows][N+1] or NULL = the ramp (1 - t/T) phi_hist[0] + (t/T) phi_T of build_targets_1d
+ *   (G1:238-241); J0_out [B][5] = {J1,J2,J3,J4,J} of the start.
+ *   iterate: optimistic step with alpha_prev, else backtracking from alpha_prev with beta 0.8 and
+ *   <= 5 trials (the first of which repeats the optimistic step and is not recomputed), alpha growth
+ *   1.2 / plateau rule (10 x |dJ| < 1e-7 -> 2.0), stop rule (relative control change < 1e-5 after
+ *   k > 10; the control is taken, state and cost keep the previous iterate, G1:462-465).
+ *   Outputs [B][n_iters], any may be NULL; trials_out as the reference counts them (1 = optimistic
+ *   step accepted); seconds_out [3] = {adjoint sweep, optimistic round, backtracking rounds}.
+ *   Returns the number of iterations performed or a negative error.
+ *   get: what = 0 control u, 1 state history, 2 adjoint r, 3 phi_Q; out [B][rows][N+1]. */
+int vch1d_pgd_init(vch1d_ctx *ctx, const double *phi0, const double *phi_T, const double *phi_Q,
+                   const double *x, const double *t_hist, int rows, const double *dt,
+                   const vch_opt_params *opt, double *J0_out);
+int vch1d_pgd_iterate(vch1d_ctx *ctx, int n_iters, double *cost_out, double *alpha_out,
+                      int32_t *trials_out, double *change_out, double *seconds_out);
+int vch1d_pgd_get(vch1d_ctx *ctx, int what, double *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -126,3 +126,43 @@ def run_optimization(fwd_config: ForwardSolverConfig, opt_config: OptimizationCo
         u_k, cost_k, phi_k = u_n.copy(), c_n, phi_n
     return dict(costs=costs, alphas=alphas, trials=trials, u=u_k, phi=phi_k, r=r_k, converged=converged,
                 phi_T=phi_T, phi_Q=phi_Q, x=x, t_hist=t_hist)
+
+
+def run_optimization_resident(fwd_config: ForwardSolverConfig, opt_config: OptimizationConfig, n_iter=None, choice_t=1,
+                              choice_q=1, initial_phi=None, seeds=None):
+    """The same loop (G1:333-477) run device-resident through `vch1d_pgd_*`: control, state history,
+    adjoint and targets never leave HBM between iterations.  `seeds` (a list) or `initial_phi`
+    ((B, N+1)) gives a batch of trajectories; default = the reference's seed 42.  Returns the same
+    dict as run_optimization, with a leading trajectory axis when batched."""
+    from ..engine import Engine1D, time_grid
+    from .Forward_solver import init_phi_random, delta_sep
+    O = opt_config
+    N = int(fwd_config.N)
+    tg, dts = time_grid(float(fwd_config.T), float(fwd_config.dt_initial))
+    t_hist = np.concatenate([[0.0], tg])
+    if initial_phi is not None:
+        phi0 = np.atleast_2d(np.asarray(initial_phi, dtype=np.float64))
+    else:
+        phi0 = np.stack([init_phi_random(N, delta_sep, amp=0.01, seed=s, enforce_zero_mean=True)
+                         for s in (seeds if seeds is not None else [42])])
+    B = phi0.shape[0]
+    eng = Engine1D(N=N, Lx=float(fwd_config.Lx), tau=float(fwd_config.tau), gamma=float(fwd_config.gamma),
+                   c1=float(fwd_config.c1), c2=float(fwd_config.c2), kappa=float(fwd_config.kappa), batch=B,
+                   max_steps=max(len(dts), 1))
+    try:
+        x = eng.x.copy()
+        phi_T = np.stack([build_targets_1d(x, t_hist, phi0[b], float(fwd_config.Lx), float(fwd_config.T),
+                                           choice_t=choice_t, choice_q=2)[0] for b in range(B)])
+        phi_Q = None if choice_q == 1 else np.zeros((B, len(t_hist), N + 1))
+        J0 = eng.pgd_init(phi0, phi_T, t_hist, dts, make_opt(O), phi_Q=phi_Q, x=x)
+        n = O.max_iter if n_iter is None else n_iter
+        res = eng.pgd_iterate(n)
+        sq = (lambda a: a[0]) if B == 1 else (lambda a: a)
+        costs = np.concatenate([J0.reshape(B, 5)[:, 4:5], res["cost"]], axis=1)
+        out = dict(costs=sq(costs), alphas=sq(res["alpha"]), trials=sq(res["trials"]), change=sq(res["change"]),
+                   iters=res["iters"], u=eng.pgd_get("u"), phi=eng.pgd_get("phi"), r=eng.pgd_get("r"),
+                   phi_T=sq(phi_T), phi_Q=eng.pgd_get("phi_Q"), x=x, t_hist=t_hist, seconds=res["seconds"])
+    finally:
+        eng.close()
+    return out
+

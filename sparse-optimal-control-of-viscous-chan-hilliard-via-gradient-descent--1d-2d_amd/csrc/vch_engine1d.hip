@@ -5,6 +5,7 @@
 #include "vch_kernels1d.h"
 #include <algorithm>
 #include <cmath>
+#include <vector>
 
 struct vch1d_ctx {
     vch1d_params prm;
@@ -21,6 +22,15 @@ struct vch1d_ctx {
     int *stats_dev, *stats_host;
     size_t lds_bytes;
     int rows_res;
+    // device-resident PGD (vch1d_pgd_*)
+    bool pgd_ready = false;
+    int pgd_rows = 0;
+    vch_opt_params opt;
+    double *phi0_dev = nullptr, *phi_trial = nullptr, *chg_dev = nullptr, *tp_dev = nullptr;
+    int *skip_dev = nullptr;
+    std::vector<double> t_host, chg_host, pgd_cost, pgd_alpha_prev;
+    std::vector<std::vector<double>> pgd_cost_hist;
+    std::vector<int> pgd_plateau, pgd_k, pgd_done;
 };
 
 #define LAUNCH1(kern, grid, block, lds, ...)                                       \
@@ -136,10 +146,11 @@ extern "C" void vch1d_destroy(vch1d_ctx *c) {
     hipStreamSynchronize(c->stream);
     double *all[] = {c->scratch, c->tmp[0], c->tmp[1], c->tmp[2], c->tmp[3], c->tmp[4], c->tmp[5], c->tmp[6], c->tmp[7],
                      c->phiT, c->dts, c->tgrid, c->wx, c->alpha_dev, c->cost_lvl, c->hist_dev, c->phi_hist, c->u_hist,
-                     c->u_trial, c->phiQ, c->p_hist, c->q_hist, c->r_hist};
+                     c->u_trial, c->phiQ, c->p_hist, c->q_hist, c->r_hist, c->phi0_dev, c->phi_trial, c->chg_dev, c->tp_dev};
     for (double *q : all)
         if (q) hipFree(q);
     hipFree(c->stats_dev);
+    if (c->skip_dev) hipFree(c->skip_dev);
     hipHostFree(c->stats_host);
     hipHostFree(c->cost_host);
     hipEventDestroy(c->ev0);
@@ -247,7 +258,7 @@ extern "C" int vch1d_forward(vch1d_ctx *c, const double *phi0, const double *u, 
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     LAUNCH1(k1d_forward, dim3(c->B), dim3(T1), c->lds_bytes, c->P, c->n, c->h, c->lvl, M, (const double *)c->dts,
             (const double *)c->tmp[0], (const double *)(u ? c->u_hist : nullptr), u_rows, hs1(c), c->phi_hist, hs1(c),
-            c->scratch, c->stats_dev);
+            c->scratch, c->stats_dev, (const int *)nullptr);
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     HIPCHK(hipMemcpyAsync(c->stats_host, c->stats_dev, sizeof(int) * 8 * c->B, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -360,3 +371,227 @@ extern "C" int vch1d_grad_prox(vch1d_ctx *c, const double *u, const double *r, i
             (const double *)c->alpha_dev, o->b3, o->kappa_sparsity, o->u_min, o->u_max, c->u_trial, (double *)nullptr);
     return down_hist(c, u_out, c->u_trial, rows);
 }
+
+// ------------------------------------------------------------------------------------
+// device-resident PGD loop (G1:333-477): control, state history, adjoint and targets stay in HBM
+// ------------------------------------------------------------------------------------
+static void trapz_x(const vch1d_ctx *c, const double *x, std::vector<double> &wx) {
+    wx.assign(c->n, 0.0);                      // np.trapezoid weights from the caller's grid (C1:57)
+    for (int i = 0; i + 1 < c->n; ++i) {
+        const double d = x[i + 1] - x[i];
+        wx[i] += 0.5 * d;
+        wx[i + 1] += 0.5 * d;
+    }
+}
+
+// J[b][5] of (phi, u) on the device; wx already uploaded
+static int cost1_core(vch1d_ctx *c, const double *phi_dev, const double *u_dev, int rows, double *J_out) {
+    const vch_opt_params *o = &c->opt;
+    LAUNCH1(k1d_cost, dim3(rows, c->B), dim3(T1), 0, c->n, rows, (const double *)c->wx, phi_dev, u_dev,
+            (const double *)c->phiQ, (const double *)c->phiT, hs1(c), c->cost_lvl);
+    VCHCHK(down(c, c->cost_host, c->cost_lvl, (size_t)c->B * rows * 4));
+    const double *t = c->t_host.data();
+    for (int b = 0; b < c->B; ++b) {
+        const double *s = c->cost_host + (size_t)b * rows * 4;
+        double i1 = 0, i3 = 0, i4 = 0;
+        for (int k = 0; k + 1 < rows; ++k) {
+            const double d = t[k + 1] - t[k];
+            i1 += d * (s[(k + 1) * 4 + 0] + s[k * 4 + 0]) / 2.0;
+            i3 += d * (s[(k + 1) * 4 + 2] + s[k * 4 + 2]) / 2.0;
+            i4 += d * (s[(k + 1) * 4 + 3] + s[k * 4 + 3]) / 2.0;
+        }
+        double *J = J_out + 5 * b;
+        J[0] = (o->b1 / 2.0) * i1;
+        J[1] = (o->b2 / 2.0) * s[(rows - 1) * 4 + 1];
+        J[2] = (o->b3 / 2.0) * i3;
+        J[3] = o->kappa_sparsity * i4;
+        J[4] = J[0] + J[1] + J[2] + J[3];
+    }
+    return 0;
+}
+
+static int fwd1_core(vch1d_ctx *c, const double *u_dev, int rows, double *hist_dev, const int *skip_dev) {
+    const int M = rows - 2;
+    LAUNCH1(k1d_forward, dim3(c->B), dim3(T1), c->lds_bytes, c->P, c->n, c->h, c->lvl, M, (const double *)c->dts,
+            (const double *)c->phi0_dev, u_dev, rows, hs1(c), hist_dev, hs1(c), c->scratch, c->stats_dev, skip_dev);
+    HIPCHK(hipMemcpyAsync(c->stats_host, c->stats_dev, sizeof(int) * 8 * c->B, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int b = 0; b < c->B; ++b)
+        if (c->stats_host[b * 8 + 4]) return vch_fail(VCH_ERR_STATE, "Non-finite mass_defect; check phi bounds/log regularization.");
+    return 0;
+}
+
+extern "C" int vch1d_pgd_init(vch1d_ctx *c, const double *phi0, const double *phi_T, const double *phi_Q, const double *x,
+                              const double *t_hist, int rows, const double *dt, const vch_opt_params *opt, double *J0_out) {
+    CTXCHK1(c);
+    ARGCHK1(phi0 && phi_T && x && t_hist && dt && opt, "NULL argument");
+    ARGCHK1(rows >= 3 && rows <= c->Mmax + 2, "rows out of range (3..max_steps+2)");
+    const int B = c->B, M = rows - 2;
+    for (int k = 0; k < M; ++k) ARGCHK1(dt[k] > 0, "dt must be positive");
+    c->opt = *opt;
+    c->pgd_rows = rows;
+    c->t_host.assign(t_hist, t_hist + rows);
+    double **hs[] = {&c->phi_hist, &c->u_hist, &c->u_trial, &c->phiQ, &c->p_hist, &c->q_hist, &c->r_hist, &c->phi_trial};
+    for (auto p : hs) VCHCHK(ensure1(c, p));
+    if (!c->phi0_dev) VCHCHK(dalloc1(&c->phi0_dev, (size_t)B * c->n, c->stream));
+    if (!c->chg_dev) VCHCHK(dalloc1(&c->chg_dev, (size_t)B * (c->Mmax + 2) * 2, c->stream));
+    if (!c->tp_dev) VCHCHK(dalloc1(&c->tp_dev, c->Mmax + 2, c->stream));
+    if (!c->skip_dev) HIPCHK(hipMalloc((void **)&c->skip_dev, sizeof(int) * B));
+    c->chg_host.assign((size_t)B * rows * 2, 0.0);
+    VCHCHK(up(c, c->phi0_dev, phi0, (size_t)B * c->n));
+    VCHCHK(up(c, c->phiT, phi_T, (size_t)B * c->n));
+    VCHCHK(up(c, c->dts, dt, M));
+    VCHCHK(up(c, c->tgrid, t_hist, rows));
+    std::vector<double> wx;
+    trapz_x(c, x, wx);
+    VCHCHK(up(c, c->wx, wx.data(), c->n));
+    HIPCHK(hipStreamSynchronize(c->stream));          // wx is a local
+    // uncontrolled march (G1:341), u = 0
+    VCHCHK(fwd1_core(c, nullptr, rows, c->phi_hist, nullptr));
+    c->rows_res = rows;
+    HIPCHK(hipMemsetAsync(c->u_hist, 0, sizeof(double) * B * hs1(c), c->stream));
+    if (phi_Q) {
+        VCHCHK(up_hist(c, c->phiQ, phi_Q, rows));
+    } else {
+        std::vector<double> tp(rows);
+        const double Tend = t_hist[rows - 1] > 0 ? t_hist[rows - 1] : 1.0;
+        for (int k = 0; k < rows; ++k) tp[k] = t_hist[k] / Tend;
+        VCHCHK(up(c, c->tp_dev, tp.data(), rows));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        LAUNCH1(k1d_ramp, dim3(rows, B), dim3(T1), 0, c->n, (const double *)c->tp_dev, (const double *)c->phi_hist,
+                (const double *)c->phiT, hs1(c), c->phiQ);
+    }
+    std::vector<double> J(5 * B);
+    VCHCHK(cost1_core(c, c->phi_hist, c->u_hist, rows, J.data()));
+    c->pgd_cost.assign(B, 0.0);
+    for (int b = 0; b < B; ++b) c->pgd_cost[b] = J[5 * b + 4];
+    if (J0_out) memcpy(J0_out, J.data(), sizeof(double) * 5 * B);
+    c->pgd_alpha_prev.assign(B, opt->alpha_max);
+    c->pgd_plateau.assign(B, 0);
+    c->pgd_k.assign(B, 0);
+    c->pgd_done.assign(B, 0);
+    c->pgd_cost_hist.assign(B, std::vector<double>());
+    for (int b = 0; b < B; ++b) c->pgd_cost_hist[b].push_back(c->pgd_cost[b]);
+    c->pgd_ready = true;
+    return 0;
+}
+
+static int copy_traj1(vch1d_ctx *c, double *dst, const double *src, int b, int rows) {
+    HIPCHK(hipMemcpyAsync(dst + b * hs1(c), src + b * hs1(c), sizeof(double) * rows * c->n, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+
+extern "C" int vch1d_pgd_iterate(vch1d_ctx *c, int n_iters, double *cost_out, double *alpha_out, int32_t *trials_out,
+                                 double *change_out, double *seconds_out) {
+    CTXCHK1(c);
+    if (!c->pgd_ready) return vch_fail(VCH_ERR_STATE, "vch1d_pgd_iterate: call vch1d_pgd_init first");
+    ARGCHK1(n_iters >= 1, "n_iters must be >= 1");
+    const int B = c->B, rows = c->pgd_rows;
+    const vch_opt_params &O = c->opt;
+    constexpr int MAX_LS = 5;                 // G1:74
+    constexpr double LS_BETA = 0.8;
+    double sec[3] = {0, 0, 0};                // backward, optimistic round, backtracking rounds
+    auto tick = [&](hipEvent_t e) { return hipEventRecord(e, c->stream); };
+    auto lap = [&]() {
+        float ms = 0;
+        hipEventSynchronize(c->ev1);
+        hipEventElapsedTime(&ms, c->ev0, c->ev1);
+        return (double)ms * 1e-3;
+    };
+    std::vector<double> alpha(B), Jt(5 * B);
+    std::vector<int> accepted(B), trials(B);
+    const size_t hb = (size_t)B * hs1(c) * sizeof(double);
+    int done_iters = 0;
+    for (int it = 0; it < n_iters; ++it) {
+        bool all_done = true;
+        for (int b = 0; b < B; ++b) all_done &= (c->pgd_done[b] != 0);
+        if (all_done) break;
+        // --- adjoint sweep (G1:356); only r is consumed
+        HIPCHK(tick(c->ev0));
+        HIPCHK(hipMemsetAsync(c->p_hist, 0, hb, c->stream));
+        HIPCHK(hipMemsetAsync(c->q_hist, 0, hb, c->stream));
+        HIPCHK(hipMemsetAsync(c->r_hist, 0, hb, c->stream));
+        LAUNCH1(k1d_backward, dim3(B), dim3(T1), c->lds_bytes, c->F, c->n, c->h, c->lvl, rows, (const double *)c->tgrid,
+                (const double *)c->phi_hist, (const double *)c->phiQ, (const double *)c->phiT, O.b1, O.b2, c->p_hist, c->q_hist,
+                c->r_hist, hs1(c), c->scratch);
+        HIPCHK(tick(c->ev1));
+        sec[0] += lap();
+        for (int b = 0; b < B; ++b) {
+            alpha[b] = c->pgd_alpha_prev[b];
+            accepted[b] = c->pgd_done[b] ? 1 : 0;
+            trials[b] = 0;
+        }
+        // round 0: optimistic step with alpha_prev (G1:365-372), which is also the first trial of the line
+        // search (alpha_init = alpha_prev, G1:383) -- that repetition is not recomputed; rounds 1..4: alpha *= 0.8
+        for (int round = 0; round < MAX_LS; ++round) {
+            HIPCHK(tick(c->ev0));
+            VCHCHK(up(c, c->alpha_dev, alpha.data(), B));
+            HIPCHK(hipMemcpyAsync(c->skip_dev, accepted.data(), sizeof(int) * B, hipMemcpyHostToDevice, c->stream));
+            LAUNCH1(k1d_grad_prox, dim3(rows, B), dim3(T1), 0, c->n, (const double *)c->u_hist, (const double *)c->r_hist, hs1(c),
+                    (const double *)c->alpha_dev, O.b3, O.kappa_sparsity, O.u_min, O.u_max, c->u_trial, c->chg_dev);
+            VCHCHK(fwd1_core(c, c->u_trial, rows, c->phi_trial, c->skip_dev));
+            VCHCHK(cost1_core(c, c->phi_trial, c->u_trial, rows, Jt.data()));
+            VCHCHK(down(c, c->chg_host.data(), c->chg_dev, (size_t)B * rows * 2));
+            HIPCHK(tick(c->ev1));
+            sec[round == 0 ? 1 : 2] += lap();
+            bool pending = false;
+            for (int b = 0; b < B; ++b) {
+                if (accepted[b]) continue;
+                trials[b] = round + 1;
+                const bool ok = Jt[5 * b + 4] < c->pgd_cost[b];
+                const bool last = (round == MAX_LS - 1);
+                if (!ok && !last) {
+                    alpha[b] *= LS_BETA;
+                    pending = true;
+                    continue;
+                }
+                accepted[b] = 1;
+                const double a_k = ok ? alpha[b] : alpha[b] * LS_BETA;     // G1:112-113 returns the once-more reduced step
+                const double c_n = Jt[5 * b + 4];
+                double d2 = 0, n2 = 0;
+                for (int r = 0; r < rows; ++r) {
+                    d2 += c->chg_host[((size_t)b * rows + r) * 2];
+                    n2 += c->chg_host[((size_t)b * rows + r) * 2 + 1];
+                }
+                const double change = std::sqrt(d2) / (std::sqrt(n2) + 1e-9);
+                const int k = c->pgd_k[b];
+                auto &ch = c->pgd_cost_hist[b];
+                ch.push_back(c_n);
+                if (k > 0 && std::fabs(ch[ch.size() - 1] - ch[ch.size() - 2]) < 1e-7) c->pgd_plateau[b]++;
+                else c->pgd_plateau[b] = 0;
+                if (c->pgd_plateau[b] >= 10) {
+                    c->pgd_alpha_prev[b] = std::min(O.alpha_max, a_k * 2.0);
+                    c->pgd_plateau[b] = 0;
+                } else {
+                    c->pgd_alpha_prev[b] = std::min(O.alpha_max, a_k * 1.2);
+                }
+                VCHCHK(copy_traj1(c, c->u_hist, c->u_trial, b, rows));
+                if (change < 1e-5 && k > 10) {
+                    c->pgd_done[b] = 1;                 // G1:462-465: u_k taken, state and cost keep the previous iterate
+                } else {
+                    VCHCHK(copy_traj1(c, c->phi_hist, c->phi_trial, b, rows));
+                    c->pgd_cost[b] = c_n;
+                }
+                c->pgd_k[b] = k + 1;
+                if (cost_out) cost_out[(long)b * n_iters + it] = c_n;
+                if (alpha_out) alpha_out[(long)b * n_iters + it] = a_k;
+                if (trials_out) trials_out[(long)b * n_iters + it] = trials[b];
+                if (change_out) change_out[(long)b * n_iters + it] = change;
+            }
+            HIPCHK(hipStreamSynchronize(c->stream));
+            if (!pending) break;
+        }
+        done_iters = it + 1;
+    }
+    if (seconds_out) memcpy(seconds_out, sec, sizeof(sec));
+    return done_iters;
+}
+
+extern "C" int vch1d_pgd_get(vch1d_ctx *c, int what, double *out) {
+    CTXCHK1(c);
+    ARGCHK1(out && what >= 0 && what <= 3, "NULL out or what not in 0..3");
+    if (!c->pgd_ready) return vch_fail(VCH_ERR_STATE, "vch1d_pgd_get: call vch1d_pgd_init first");
+    const double *src = what == 0 ? c->u_hist : what == 1 ? c->phi_hist : what == 2 ? c->r_hist : c->phiQ;
+    return down_hist(c, out, src, c->pgd_rows);
+}
+

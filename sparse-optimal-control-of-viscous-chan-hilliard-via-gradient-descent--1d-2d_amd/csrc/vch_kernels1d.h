@@ -367,10 +367,12 @@ __device__ void newton1(const Phys1 &P, int n, double h, double dt, int lvl, Scr
 __global__ __launch_bounds__(T1) void k1d_forward(Phys1 P, int n, double h, int lvl, int M, const double *__restrict__ dts,
                                                   const double *__restrict__ phi0, const double *u, int u_rows,
                                                   long u_stride, double *__restrict__ hist, long hist_stride,
-                                                  double *scratch, int *__restrict__ stats /* [B][8] */) {
+                                                  double *scratch, int *__restrict__ stats /* [B][8] */,
+                                                  const int *__restrict__ skip /* [B] or NULL */) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ double s4[T1 / 64];
     const int b = blockIdx.x, tid = threadIdx.x;
+    if (skip && skip[b]) return;            // line search already over for this trajectory (G1:98-108)
     Scr1 S = scr_of(scratch, b, n);
     const double a = 1.0 / (h * h);
     // phi = phi0, w = 0, mu = initialize_mu(phi, w) (F1:316-324), history rows 0 and 1 (F1:329-336)
@@ -573,3 +575,13 @@ __global__ __launch_bounds__(T1) void k1d_grad_prox(int n, const double *__restr
     d2 = block_red<0>(d2, s4); n2 = block_red<0>(n2, s4);
     if (chg && threadIdx.x == 0) { chg[((long)b * rows + row) * 2] = d2; chg[((long)b * rows + row) * 2 + 1] = n2; }
 }
+
+// phi_Q = (1 - t/T) phi_initial + (t/T) phi_T, phi_initial = history row 0 (build_targets_1d, G1:238-241)
+__global__ __launch_bounds__(T1) void k1d_ramp(int n, const double *__restrict__ tp, const double *__restrict__ phi_hist,
+                                               const double *__restrict__ phiT, long hs, double *__restrict__ phiQ) {
+    const int row = blockIdx.x, b = blockIdx.y;
+    const double f = tp[row];
+    for (int i = threadIdx.x; i < n; i += T1)
+        phiQ[b * hs + (long)row * n + i] = (1.0 - f) * phi_hist[b * hs + i] + f * phiT[(long)b * n + i];
+}
+

@@ -444,3 +444,38 @@ class Engine1D:
         o = opt if isinstance(opt, OptParams) else make_opt(opt)
         check(self.lib.vch1d_grad_prox(self.ctx, _dp(u), _dp(r), int(u.shape[1]), _dp(al), C.byref(o), _dp(out)))
         return self._sq(out)
+
+    # -- device-resident PGD (G1:333-477) ----------------------------------------------------
+    def pgd_init(self, phi0, phi_T, t_hist, dt, opt, phi_Q=None, x=None):
+        """Uncontrolled march + targets + J0; t_hist has M+2 entries, dt M.  Returns J0 (B, 5)."""
+        phi0, phi_T = self._fld(phi0, "phi0"), self._fld(phi_T, "phi_T_target")
+        t_hist = np.ascontiguousarray(t_hist, dtype=np.float64)
+        dt = np.ascontiguousarray(dt, dtype=np.float64)
+        rows = int(t_hist.size)
+        if dt.size != rows - 2:
+            raise ValueError(f"dt must have len(t_hist) - 2 = {rows - 2} entries, got {dt.size}")
+        pq = None if phi_Q is None else self._hist(phi_Q, rows, "phi_Q_target")
+        x = np.ascontiguousarray(self.x if x is None else x, dtype=np.float64)
+        o = opt if isinstance(opt, OptParams) else make_opt(opt)
+        J0 = np.empty((self.B, 5))
+        check(self.lib.vch1d_pgd_init(self.ctx, _dp(phi0), _dp(phi_T), _dp(pq), _dp(x), _dp(t_hist), rows, _dp(dt),
+                                      C.byref(o), _dp(J0)))
+        self._pgd_rows = rows
+        return J0
+
+    def pgd_iterate(self, n_iters):
+        n = int(n_iters)
+        cost = np.full((self.B, n), np.nan)
+        alpha = np.full((self.B, n), np.nan)
+        trials = np.zeros((self.B, n), dtype=np.int32)
+        chg = np.full((self.B, n), np.nan)
+        sec = np.zeros(3)
+        done = check(self.lib.vch1d_pgd_iterate(self.ctx, n, _dp(cost), _dp(alpha), trials.ctypes.data_as(_lib._I32),
+                                                _dp(chg), _dp(sec)))
+        return dict(iters=done, cost=cost, alpha=alpha, trials=trials, change=chg,
+                    seconds=dict(zip(("backward", "optimistic", "backtracking"), sec)))
+
+    def pgd_get(self, what):
+        out = np.empty((self.B, self._pgd_rows, self.n))
+        check(self.lib.vch1d_pgd_get(self.ctx, {"u": 0, "phi": 1, "r": 2, "phi_Q": 3}[what], _dp(out)))
+        return self._sq(out)

@@ -152,3 +152,48 @@ def test_n4096_roundoff_regime(V, O1):
     ph, st = ef.forward(phi0, dts)
     w = O1.trapz_weights(N + 1) / N
     assert np.max(np.abs(ph @ w - (ph @ w)[0])) <= 1e-12 and np.all(np.isfinite(ph))
+
+
+# ---------------------------------------------------------------------------------------
+# device-resident PGD (vch1d_pgd_*)
+# ---------------------------------------------------------------------------------------
+def test_pgd_resident_vs_reference_golden(V):
+    """The device-resident loop against PGD iterations made with the reference's own functions
+    (incl. a forced backtracking case): costs, steps, trial counts, final control/state, targets."""
+    G1 = V.module("Vch_control_1D.GD_1D")
+    K1 = V.module("Vch_control_1D.config")
+    for tag in ("32", "32_bt"):
+        gp = golden(f"g1d_pgd_{tag}.npz")
+        cfg = K1.ForwardSolverConfig(N=int(gp["N"]), T=float(gp["T"]), dt_initial=float(gp["dt"]))
+        opt = K1.OptimizationConfig(alpha_max=float(gp["alpha_max"]))
+        res = G1.run_optimization_resident(cfg, opt, n_iter=int(gp["n_iter"]))
+        assert np.allclose(res["costs"], gp["costs"], rtol=1e-9), (res["costs"], gp["costs"])
+        assert np.allclose(res["alphas"], gp["alphas"], rtol=1e-14) and list(res["trials"]) == list(gp["trials"])
+        assert relerr(res["u"], gp["u_final"]) < 1e-8 and relerr(res["phi"], gp["phi_final"]) < 1e-8
+        assert relerr(res["phi_Q"], gp["phi_Q"]) < 1e-15 and relerr(res["r"], gp["r_last"]) < 1e-8
+        assert np.allclose(res["t_hist"], gp["t_hist"], rtol=0, atol=0)
+
+
+def test_pgd_resident_batch_matches_function_seam(V):
+    """A batch of three seeds (line searches of different length, the accepted trajectories skipping
+    the remaining trial marches) against the function-seam loop run seed by seed."""
+    G1 = V.module("Vch_control_1D.GD_1D")
+    K1 = V.module("Vch_control_1D.config")
+    F1 = V.module("Vch_control_1D.Forward_solver")
+    cfg = K1.ForwardSolverConfig(N=48, T=0.08, dt_initial=1e-2)
+    opt = K1.OptimizationConfig(alpha_max=2.0e5)
+    seeds = [42, 43, 44]
+    phi0 = np.stack([F1.init_phi_random(48, 1e-2, amp=a, seed=s) for s, a in zip(seeds, (0.01, 0.2, 0.05))])
+    rb = G1.run_optimization_resident(cfg, opt, n_iter=3, initial_phi=phi0)
+    assert rb["u"].shape == (3, 10, 49)
+    assert len({tuple(t) for t in rb["trials"]}) > 1, rb["trials"]        # the searches really differ
+    for b in range(3):
+        r1 = G1.run_optimization_resident(cfg, opt, n_iter=3, initial_phi=phi0[b])
+        assert np.array_equal(rb["trials"][b], r1["trials"])
+        assert np.allclose(rb["costs"][b], r1["costs"], rtol=1e-13)
+        assert relerr(rb["u"][b], r1["u"]) < 1e-12 and relerr(rb["phi"][b], r1["phi"]) < 1e-12
+    # seed 42 is the reference's own start: the function-seam loop must agree too
+    rs = G1.run_optimization(cfg, opt, n_iter=3)
+    assert list(rs["trials"]) == list(rb["trials"][0])
+    assert np.allclose(rs["costs"], rb["costs"][0], rtol=1e-12)
+    assert relerr(rs["u"], rb["u"][0]) < 1e-10
