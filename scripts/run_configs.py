@@ -58,4 +58,13 @@ if 2 in which:      # 1D N = 4096, 1000 time steps, single trajectory: forward +
     t1 = time.perf_counter(); p, q, r = B1.run_backward(ph, x, t, 5.0, 10.0, phi_Q, phi_T); wb = time.perf_counter() - t1
     out["config2_1d_4096_1000"] = dict(rows=int(ph.shape[0]), forward_s=w, backward_s=wb, finite=bool(np.isfinite(ph).all() and np.isfinite(r).all()),
                                        mass_drift=float(np.abs(ph @ F1.trapz_weights(4097) / 4096 - (ph[0] @ F1.trapz_weights(4097)) / 4096).max()))
+    # device-resident PGD iterations at the same size: one trajectory, then a batch of 64 seeds
+    O1 = K1.OptimizationConfig()
+    for seeds in ([42], list(range(42, 106))):
+        t0 = time.perf_counter()
+        res = G1.run_optimization_resident(cfg, O1, n_iter=2, seeds=seeds)
+        w = time.perf_counter() - t0
+        out[f"config2_pgd_resident_batch{len(seeds)}"] = dict(
+            wall_s_incl_initial_march=w, seconds=res["seconds"], trials=np.asarray(res["trials"]).tolist()[:4],
+            costs=np.asarray(res["costs"]).tolist()[:2])
 print(json.dumps(out, indent=1))
