@@ -425,3 +425,48 @@ def test_pgd_eight_iterations_vs_oracle(V, O2):
         assert list(out["attempts"][b]) == list(r.attempts)
         assert relerr(u[b], r.u) < 1e-6
     assert np.all(np.diff(np.concatenate([J0[:, 4:5], out["cost"]], axis=1), axis=1) < 0)      # monotone descent
+
+
+def test_full_size_pgd_iteration_invariants_512x1000(V, O2):
+    """BASELINE config 4 at full size for one trajectory (512^2, 1000 steps of 1e-3): size-independent
+    properties of one device-resident PGD iteration -- the cost decreases, the controlled and the
+    uncontrolled state conserve mass (phi_t = Lap mu whatever the control) and stay inside the clip
+    band, the uncontrolled free energy does not increase, the adjoint vanishes at t = T (B2:187) and
+    the accepted control respects the box and the prox fixed-point structure."""
+    F2 = V.module("Vch_control_2D.Forward2_solver")
+    N, M = 512, 1000
+    t, dts = V.time_grid(1.0, 1e-3)
+    assert len(dts) == M
+    e = V.Engine2D(Nx=N, Ny=N, batch=1, max_steps=M)
+    xs = np.linspace(0, 1, N + 1)
+    phi_T = 0.7 * np.sin(2 * np.pi * xs)[:, None] * np.cos(np.pi * xs)[None, :]
+    phi0 = F2.init_phi_random(N, N, 1e-2, amp=0.1, seed=42)
+    opt = V.make_opt()
+    J0 = e.pgd_init(phi0, phi_T, t, opt, ramp=True, T=1.0)
+    wts = np.outer(F2.trapz_weights(N + 1), F2.trapz_weights(N + 1))
+    ph = e.pgd_get("phi")                     # uncontrolled march
+    assert ph.shape == (M + 1, N + 1, N + 1) and np.array_equal(ph[0], phi0)
+    lv = list(range(0, M + 1, 50))
+    mass = np.array([np.sum(wts * ph[k]) for k in lv])
+    assert np.abs(mass - mass[0]).max() <= 1e-10 * np.sum(wts)
+    assert np.abs(ph).max() <= 0.99 + 1e-15 and np.isfinite(ph).all()
+    E = np.array([F2.free_energy(ph[k], 1e-4, 0.75, 1.0, 1 / N, 1 / N) for k in lv])
+    assert np.all(np.diff(E) <= 1e-9) and E[-1] < E[0]
+    del ph
+    res = e.pgd_iterate(1)
+    assert res["iters"] == 1 and res["cost"][0, 0] < J0[0, 4]
+    assert 0 <= res["attempts"][0, 0] <= 10 and res["alpha"][0, 0] <= 50.0
+    r = e.pgd_get("r")
+    assert np.isfinite(r).all() and not r[M].any() and np.abs(r[0]).max() > 0
+    u = e.pgd_get("u")
+    assert u.min() >= -1.0 and u.max() <= 1.0
+    # prox structure of u = clip(soft(0 - alpha (r + b3*0), alpha*kappa_s)): zero exactly where |alpha r| <= alpha kappa_s
+    a = res["alpha"][0, 0]
+    zero = np.abs(a * r) <= a * 1e-4
+    assert not u[zero].any() and np.all(u[~zero] != 0)
+    del r, u
+    ph = e.pgd_get("phi")                     # controlled state of the accepted step
+    mass = np.array([np.sum(wts * ph[k]) for k in lv])
+    assert np.abs(mass - mass[0]).max() <= 1e-10 * np.sum(wts)
+    assert np.abs(ph).max() <= 0.99 + 1e-15
+
