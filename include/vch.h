@@ -192,6 +192,14 @@ int vch2d_pgd_cost_dev(vch2d_ctx *ctx, double **ptr_dev);
 
 #define VCH_RESIDENT ((const double *)(uintptr_t)1)
 
+/* Replaces free_energy (F2:256-319) for every level of a history at once (the mass/energy
+ * invariants of the reference's tests, T2f:252-279): phi_hist [B][rows][Nx+1][Ny+1] or
+ * VCH_RESIDENT (the state history of the last march), w_hist the coupling field (same shape) or
+ * NULL, eps <= 0 -> 1e-8.  The array is taken as the reference takes it: axis 0 with hy, axis 1
+ * with hx.  E_out [B][rows]. */
+int vch2d_free_energy(vch2d_ctx *ctx, const double *phi_hist, int rows, const double *w_hist,
+                      double hx, double hy, double eps, double *E_out);
+
 /* -- in-situ kernel timing (used by bench.py for the roofline figure; no reference counterpart) --
  * Between _begin and _end every launch of the profiled kernel classes is bracketed by a HIP event
  * pair on the engine's stream (at most max_launches pairs).  _end returns, per class, the summed
@@ -249,6 +257,10 @@ int vch1d_cost(vch1d_ctx *ctx, const double *phi_hist, const double *u, const do
  * (C1:86-112, G1:56-71). */
 int vch1d_grad_prox(vch1d_ctx *ctx, const double *u, const double *r, int rows, const double *alpha,
                     const vch_opt_params *opt, double *u_out);
+
+/* Replaces free_energy (F1:243-262) for every level of a history; E_out [B][rows]. */
+int vch1d_free_energy(vch1d_ctx *ctx, const double *phi_hist, int rows, const double *w_hist, double h,
+                      double eps, double *E_out);
 
 /* Device-resident PGD loop of the 1D driver (the __main__ block of GD_1D.py, G1:333-477, with
  * perform_backtracking_line_search G1:73-113): control, state history, adjoint and targets stay in

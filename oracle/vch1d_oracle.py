@@ -167,6 +167,19 @@ def _solve_newton_banded(pn, dt, P, h, R):
     return np.concatenate([sol[0::2], sol[1::2]])
 
 
+def free_energy(phi, kappa, c1, c2, h, w=None, eps=None):
+    """Discrete free energy with forward-difference gradient (F1:243-262)."""
+    phi = np.asarray(phi)
+    wts = trapz_weights(len(phi))
+    E = (kappa / (2.0 * h)) * np.sum(np.diff(phi) ** 2)
+    eps = 1e-8 if eps is None else eps
+    p = np.clip(phi, -1 + eps, 1 - eps)
+    E += h * np.dot(wts, c1 * ((1 + p) * np.log(1 + p) + (1 - p) * np.log(1 - p)) - c2 * p ** 2)
+    if w is not None:
+        E -= h * np.dot(wts, np.asarray(w) * phi)
+    return E
+
+
 def init_phi_random(N, delta_sep=DELTA_SEP, amp=0.1, seed=42, enforce_zero_mean=True):
     """F1:264-277."""
     rng = np.random.default_rng(seed)

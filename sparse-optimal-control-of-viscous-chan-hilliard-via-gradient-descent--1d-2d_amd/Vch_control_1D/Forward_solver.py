@@ -104,15 +104,17 @@ def trapz_weights(n_nodes: int):
 
 
 def free_energy(phi, kappa, c1, c2, h, w=None, eps=None):
-    """F1:243-262 (diagnostic reduction, host)."""
-    wts = trapz_weights(len(phi))
-    E = (kappa / (2.0 * h)) * np.sum(np.diff(phi) ** 2)
-    eps = 1e-8 if eps is None else eps
-    p = np.clip(phi, -1 + eps, 1 - eps)
-    E += h * np.dot(wts, c1 * ((1 + p) * np.log(1 + p) + (1 - p) * np.log(1 - p)) - c2 * p ** 2)
-    if w is not None:
-        E -= h * np.dot(wts, w * phi)
-    return E
+    """F1:243-262 for one field, as a device reduction (`vch1d_free_energy`)."""
+    return float(free_energy_history(np.asarray(phi)[None], kappa, c1, c2, h,
+                                     w_hist=None if w is None else np.asarray(w)[None], eps=eps)[0])
+
+
+def free_energy_history(phi_hist, kappa, c1, c2, h, w_hist=None, eps=None):
+    """free_energy of every row of a (rows, N+1) history in one launch -> (rows,)."""
+    a = np.asarray(phi_hist, dtype=np.float64)
+    rows, n = a.shape
+    eng = engine_for(n - 1, h * (n - 1), c1=c1, c2=c2, kappa=kappa, max_steps=max(rows, 1))
+    return np.atleast_1d(eng.free_energy(a, h=h, w_hist=w_hist, eps=eps))
 
 
 def init_phi_random(N, delta_sep, amp=0.1, seed=42, enforce_zero_mean=True):

@@ -123,19 +123,18 @@ def trapz_weights(n_nodes):
 
 
 def free_energy(phi, kappa, c1, c2, hx, hy, w=None, eps=None):
-    """Discrete free energy (F2:256-319): a diagnostic reduction over one field, evaluated on
-    the host (SURVEY 8f item 4 lists the device version as 'next')."""
-    eps = 1e-8 if eps is None else eps
-    a = np.asarray(phi)
-    wts = np.outer(trapz_weights(a.shape[0]), trapz_weights(a.shape[1]))
-    Eg = (kappa / (2.0 * hy)) * np.sum(np.diff(a, axis=0) ** 2) * hx + \
-         (kappa / (2.0 * hx)) * np.sum(np.diff(a, axis=1) ** 2) * hy
-    p = np.clip(a, -1.0 + eps, 1.0 - eps)
-    psi = c1 * ((1.0 + p) * np.log(1.0 + p) + (1.0 - p) * np.log(1.0 - p)) - c2 * p ** 2
-    E = Eg + hx * hy * np.sum(wts * psi)
-    if w is not None:
-        E -= hx * hy * np.sum(wts * np.asarray(w) * a)
-    return E
+    """Discrete free energy (F2:256-319) of one field, as a device reduction (`vch2d_free_energy`).
+    The array is taken as the reference takes it: axis 0 with hy, axis 1 with hx."""
+    return float(free_energy_history(np.asarray(phi)[None], kappa, c1, c2, hx, hy,
+                                     w_hist=None if w is None else np.asarray(w)[None], eps=eps)[0])
+
+
+def free_energy_history(phi_hist, kappa, c1, c2, hx, hy, w_hist=None, eps=None):
+    """free_energy of every level of a (rows, A0, A1) history in one launch -> (rows,)."""
+    a = np.asarray(phi_hist, dtype=np.float64)
+    rows, A0, A1 = a.shape
+    eng = engine_for(A0 - 1, A1 - 1, 1.0, 1.0, 0.05, 10.0, c1, c2, kappa, max_steps=max(rows - 1, 1))
+    return np.atleast_1d(eng.free_energy(a, hx=hx, hy=hy, w_hist=w_hist, eps=eps))
 
 
 def instability_report(c1, c2, kappa, tau, Lx, Nmodes=12):

@@ -124,6 +124,8 @@ SIGNATURES = {
     "vch1d_backward": (C.c_int, [_P, _D, C.c_int, _D, C.c_double, C.c_double, C.c_double, _D, _D, _D, _D, _D]),
     "vch1d_cost": (C.c_int, [_P, _D, _D, _D, _D, C.c_int, _D, _D, C.POINTER(OptParams), _D]),
     "vch1d_grad_prox": (C.c_int, [_P, _D, _D, C.c_int, _D, C.POINTER(OptParams), _D]),
+    "vch2d_free_energy": (C.c_int, [_P, _D, C.c_int, _D, C.c_double, C.c_double, C.c_double, _D]),
+    "vch1d_free_energy": (C.c_int, [_P, _D, C.c_int, _D, C.c_double, C.c_double, _D]),
     "vch1d_pgd_init": (C.c_int, [_P, _D, _D, _D, _D, _D, C.c_int, _D, C.POINTER(OptParams), _D]),
     "vch1d_pgd_iterate": (C.c_int, [_P, C.c_int, _D, _D, _I32, _D, _D]),
     "vch1d_pgd_get": (C.c_int, [_P, C.c_int, _D]),

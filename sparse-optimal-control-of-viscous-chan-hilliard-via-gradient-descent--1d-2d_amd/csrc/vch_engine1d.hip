@@ -372,6 +372,29 @@ extern "C" int vch1d_grad_prox(vch1d_ctx *c, const double *u, const double *r, i
     return down_hist(c, u_out, c->u_trial, rows);
 }
 
+extern "C" int vch1d_free_energy(vch1d_ctx *c, const double *phi_hist, int rows, const double *w_hist, double h, double eps,
+                                 double *E_out) {
+    CTXCHK1(c);
+    ARGCHK1(phi_hist && E_out && rows >= 1 && rows <= c->Mmax + 2 && h > 0, "NULL argument, rows out of range or h <= 0");
+    VCHCHK(ensure1(c, &c->phi_hist));
+    VCHCHK(up_hist(c, c->phi_hist, phi_hist, rows));
+    c->rows_res = rows;
+    if (w_hist) {
+        VCHCHK(ensure1(c, &c->u_trial));
+        VCHCHK(up_hist(c, c->u_trial, w_hist, rows));
+    }
+    LAUNCH1(k1d_energy, dim3(rows, c->B), dim3(T1), 0, c->n, c->P.c1, c->P.c2, eps > 0 ? eps : 1e-8, (const double *)c->phi_hist,
+            (const double *)(w_hist ? c->u_trial : nullptr), hs1(c), c->cost_lvl);
+    VCHCHK(down(c, c->cost_host, c->cost_lvl, (size_t)c->B * rows * 4));
+    for (long k = 0; k < (long)c->B * rows; ++k) {
+        const double *s = c->cost_host + 4 * k;
+        double E = (c->P.kappa / (2.0 * h)) * s[0] + h * s[1];
+        if (w_hist) E -= h * s[2];
+        E_out[k] = E;
+    }
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------
 // device-resident PGD loop (G1:333-477): control, state history, adjoint and targets stay in HBM
 // ------------------------------------------------------------------------------------

@@ -1018,6 +1018,48 @@ extern "C" int vch2d_cost(vch2d_ctx *c, const double *phi_hist, const double *u,
     return cost_core(c, c->phi_hist, ud, pq, pt, false, M, t_hist, opt, J_out);
 }
 
+extern "C" int vch2d_free_energy(vch2d_ctx *c, const double *phi_hist, int rows, const double *w_hist, double hx, double hy,
+                                 double eps, double *E_out) {
+    CTXCHK(c);
+    ARGCHK(phi_hist && E_out && rows >= 1 && rows <= c->Mmax + 1 && hx > 0 && hy > 0, "NULL argument, rows out of range or h <= 0");
+    const double *pd = nullptr, *wd = nullptr;
+    if (phi_hist == VCH_RESIDENT) {
+        ARGCHK(c->phi_hist && c->M_res + 1 >= rows, "no resident state history with that many levels");
+        pd = c->phi_hist;
+    } else {
+        VCHCHK(ensure_hist(c, &c->phi_hist));
+        VCHCHK(h2d_hist(c, c->phi_hist, phi_hist, rows));
+        c->M_res = rows - 1;
+        pd = c->phi_hist;
+    }
+    if (w_hist) {                      // the coupling field travels through the trial-state buffer
+        VCHCHK(ensure_hist(c, &c->phi_trial));
+        VCHCHK(h2d_hist(c, c->phi_trial, w_hist, rows));
+        wd = c->phi_trial;
+    }
+    const int ntiles = c->nblk, A0 = c->prm.Nx + 1, A1 = c->prm.Ny + 1;
+    if (!c->cost_part) {
+        const size_t n = (size_t)c->B * (c->Mmax + 1) * ntiles * 4;
+        HIPCHK(hipMalloc((void **)&c->cost_part, n * 8));
+        HIPCHK(hipMalloc((void **)&c->cost_lvl, (size_t)c->B * (c->Mmax + 1) * 4 * 8));
+        HIPCHK(hipHostMalloc((void **)&c->cost_lvl_host, (size_t)c->B * (c->Mmax + 1) * 4 * 8));
+    }
+    const int nt = (A0 * A1 + 1023) / 1024;            // <= tiles_f * tiles_s
+    LAUNCH(k_energy, dim3(nt, rows, c->B), dim3(NTH), c->G, A0, A1, c->P.c1, c->P.c2, eps > 0 ? eps : 1e-8, pd, wd,
+           hist_stride(c), c->cost_part);
+    LAUNCH(k_cost_fin, dim3(c->B * rows), dim3(64), nt, (const double *)c->cost_part, c->cost_lvl);
+    HIPCHK(hipMemcpyAsync(c->cost_lvl_host, c->cost_lvl, (size_t)c->B * rows * 4 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (long k = 0; k < (long)c->B * rows; ++k) {
+        const double *s = c->cost_lvl_host + 4 * k;
+        // axis 0 carries hy and axis 1 carries hx, as the reference labels them (F2:293-302)
+        double E = (c->P.kappa / (2.0 * hy)) * s[0] * hx + (c->P.kappa / (2.0 * hx)) * s[1] * hy + hx * hy * s[2];
+        if (w_hist) E -= hx * hy * s[3];
+        E_out[k] = E;
+    }
+    return 0;
+}
+
 // u_out = prox(u - alpha (r + b3 u)); change_out [B][2] = {sum (u+ - u)^2, sum u^2} or NULL
 static int grad_prox_core(vch2d_ctx *c, const double *u_dev, const double *r_dev, int rows, const double *alpha_host,
                           const vch_opt_params *o, double *uout_dev, double *change_out) {

@@ -585,3 +585,25 @@ __global__ __launch_bounds__(T1) void k1d_ramp(int n, const double *__restrict__
         phiQ[b * hs + (long)row * n + i] = (1.0 - f) * phi_hist[b * hs + i] + f * phiT[(long)b * n + i];
 }
 
+// free energy of every level of a history (F1:243-262): partial sums {sum dphi^2, sum W psi, sum W w phi}
+__global__ __launch_bounds__(T1) void k1d_energy(int n, double c1, double c2, double eps, const double *__restrict__ phi,
+                                                 const double *__restrict__ w, long hs, double *__restrict__ out) {
+    __shared__ double s4[T1 / 64];
+    const int row = blockIdx.x, b = blockIdx.y, rows = gridDim.x;
+    const long o = b * hs + (long)row * n;
+    double a0 = 0, a1 = 0, a2 = 0;
+    for (int i = threadIdx.x; i < n; i += T1) {
+        const double a = phi[o + i];
+        if (i + 1 < n) { const double d = phi[o + i + 1] - a; a0 += d * d; }
+        const double wt = (i == 0 || i == n - 1) ? 0.5 : 1.0;
+        const double p = fmin(fmax(a, -1.0 + eps), 1.0 - eps);
+        a1 += wt * (c1 * ((1.0 + p) * log(1.0 + p) + (1.0 - p) * log(1.0 - p)) - c2 * (p * p));
+        if (w) a2 += wt * (w[o + i] * a);
+    }
+    a0 = block_red<0>(a0, s4); a1 = block_red<0>(a1, s4); a2 = block_red<0>(a2, s4);
+    if (threadIdx.x == 0) {
+        double *q = out + ((long)b * rows + row) * 4;
+        q[0] = a0; q[1] = a1; q[2] = a2; q[3] = 0.0;
+    }
+}
+

@@ -732,6 +732,42 @@ __global__ __launch_bounds__(NTH) void k_cost(Geom G, int tiles_f, const double 
     block_reduce_store<4>(acc, op, sred, part + (((long)b * gridDim.y + lvl) * gridDim.x + blockIdx.x) * 4);
 }
 
+// ---------------------------------------------------------------------------------
+// Free energy of every level of a history (F2:256-319), the array taken as the reference takes it:
+// shape (A0, A1) row-major, forward differences along both axes, trapezoid weights outer(A0, A1).
+// The engine stores that row-major block as ns rows of nf (flat index f -> (f / nf, f % nf), pitched).
+// Per workgroup (1024 flat nodes) partials {sum d0^2, sum d1^2, sum W psi, sum W w phi}.
+// grid = (ceil(A0*A1/1024), levels, B)
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTH) void k_energy(Geom G, int A0, int A1, double c1, double c2, double eps,
+                                                const double *__restrict__ phi, const double *__restrict__ w,
+                                                long hist_stride, double *__restrict__ part) {
+    __shared__ double sred[NPART * 4];
+    const int b = blockIdx.z, lvl = blockIdx.y;
+    const long base = b * hist_stride + (long)lvl * G.plane;
+    const double *ph = phi + base;
+    const double *wp = w ? w + base : nullptr;
+    auto at = [&](const double *p, int f) { return p[(long)(f / G.nf) * G.pitch + (f % G.nf)]; };
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    const int total = A0 * A1;
+    for (int k = 0; k < 4; ++k) {
+        const int f = blockIdx.x * 1024 + k * NTH + threadIdx.x;
+        if (f < total) {
+            const int i = f / A1, j = f - i * A1;
+            const double a = at(ph, f);
+            if (i + 1 < A0) { const double d = at(ph, f + A1) - a; acc[0] += d * d; }
+            if (j + 1 < A1) { const double d = at(ph, f + 1) - a; acc[1] += d * d; }
+            const double wt = ((i == 0 || i == A0 - 1) ? 0.5 : 1.0) * ((j == 0 || j == A1 - 1) ? 0.5 : 1.0);
+            const double p = fmin(fmax(a, -1.0 + eps), 1.0 - eps);
+            const double psi = c1 * ((1.0 + p) * log(1.0 + p) + (1.0 - p) * log(1.0 - p)) - c2 * (p * p);
+            acc[2] += wt * psi;
+            if (wp) acc[3] += wt * at(wp, f) * a;
+        }
+    }
+    const int op[4] = {0, 0, 0, 0};
+    block_reduce_store<4>(acc, op, sred, part + (((long)b * gridDim.y + lvl) * gridDim.x + blockIdx.x) * 4);
+}
+
 // sums the tile partials of k_cost: out[b][lvl][4]
 __global__ void k_cost_fin(int ntiles, const double *__restrict__ part, double *__restrict__ out) {
     const long idx = (long)blockIdx.x;      // b * levels + lvl

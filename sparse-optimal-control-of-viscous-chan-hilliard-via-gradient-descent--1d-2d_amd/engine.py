@@ -294,6 +294,34 @@ class Engine2D:
         check(self.lib.vch2d_pgd_cost_dev(self.ctx, C.byref(p)))
         return p.value
 
+    def free_energy(self, phi_hist, hx=None, hy=None, w_hist=None, eps=None):
+        """Free energy of every level (F2:256-319): phi_hist (B, rows, Nx+1, Ny+1) or "resident".
+        Returns (B, rows) (or (rows,) for one trajectory)."""
+        hx = float(self.x[1] - self.x[0]) if hx is None else float(hx)
+        hy = float(self.y[1] - self.y[0]) if hy is None else float(hy)
+        if isinstance(phi_hist, str) and phi_hist == "resident":
+            if w_hist is None:
+                raise ValueError("free_energy('resident') needs the number of levels: pass w_hist or use free_energy_resident(rows)")
+            ph, rows = C.cast(C.c_void_p(1), _lib._D), None
+        else:
+            ph = self._hist(phi_hist, 0, "phi_hist")
+            rows = int(ph.shape[1])
+        wh = None if w_hist is None else self._hist(w_hist, rows or 0, "w_hist")
+        if rows is None:
+            rows = int(wh.shape[1])
+        E = np.empty((self.B, rows))
+        check(self.lib.vch2d_free_energy(self.ctx, ph if not isinstance(ph, np.ndarray) else _dp(ph), rows, _dp(wh), hx, hy,
+                                         float(eps or 0.0), _dp(E)))
+        return self._sq(E)
+
+    def free_energy_resident(self, rows, hx=None, hy=None, eps=None):
+        """Free energy of the first `rows` levels of the state history left by the last march."""
+        hx = float(self.x[1] - self.x[0]) if hx is None else float(hx)
+        hy = float(self.y[1] - self.y[0]) if hy is None else float(hy)
+        E = np.empty((self.B, int(rows)))
+        check(self.lib.vch2d_free_energy(self.ctx, C.cast(C.c_void_p(1), _lib._D), int(rows), None, hx, hy, float(eps or 0.0), _dp(E)))
+        return self._sq(E)
+
     # -- in-situ kernel timing -------------------------------------------------------------
     PROF_CLASSES = ("schur_p", "dct", "residual", "adj_q", "cg_update", "adj_rhs", "cost", "prox")
 
@@ -444,6 +472,16 @@ class Engine1D:
         o = opt if isinstance(opt, OptParams) else make_opt(opt)
         check(self.lib.vch1d_grad_prox(self.ctx, _dp(u), _dp(r), int(u.shape[1]), _dp(al), C.byref(o), _dp(out)))
         return self._sq(out)
+
+    def free_energy(self, phi_hist, h=None, w_hist=None, eps=None):
+        """Free energy of every level (F1:243-262): phi_hist (B, rows, N+1) -> (B, rows)."""
+        ph = self._hist(phi_hist, 0, "phi_hist")
+        rows = int(ph.shape[1])
+        wh = None if w_hist is None else self._hist(w_hist, rows, "w_hist")
+        h = float(self.x[1] - self.x[0]) if h is None else float(h)
+        E = np.empty((self.B, rows))
+        check(self.lib.vch1d_free_energy(self.ctx, _dp(ph), rows, _dp(wh), h, float(eps or 0.0), _dp(E)))
+        return self._sq(E)
 
     # -- device-resident PGD (G1:333-477) ----------------------------------------------------
     def pgd_init(self, phi0, phi_T, t_hist, dt, opt, phi_Q=None, x=None):

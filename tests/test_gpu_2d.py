@@ -450,7 +450,8 @@ def test_full_size_pgd_iteration_invariants_512x1000(V, O2):
     mass = np.array([np.sum(wts * ph[k]) for k in lv])
     assert np.abs(mass - mass[0]).max() <= 1e-10 * np.sum(wts)
     assert np.abs(ph).max() <= 0.99 + 1e-15 and np.isfinite(ph).all()
-    E = np.array([F2.free_energy(ph[k], 1e-4, 0.75, 1.0, 1 / N, 1 / N) for k in lv])
+    E = e.free_energy_resident(M + 1)[lv]          # device reduction over the resident history (vch2d_free_energy)
+    assert abs(E[3] - O2.free_energy(ph[lv[3]], 1e-4, 0.75, 1.0, 1 / N, 1 / N)) < 1e-12 * abs(E[3])
     assert np.all(np.diff(E) <= 1e-9) and E[-1] < E[0]
     del ph
     res = e.pgd_iterate(1)

@@ -143,3 +143,33 @@ def test_second_order_and_sparsity_diagnostics(V):
                                                o.b3, o.kappa_sparsity, gp["phi_Q"], gp["phi_T"], o.u_min, o.u_max,
                                                num_directions=3, epsilon=1e-4, seed=42)
     assert np.allclose(d2, gs["d2"], rtol=1e-5), (d2, gs["d2"])
+
+
+def test_free_energy_device_reduction(V):
+    """free_energy (F2:256-319, F1:243-262) as a device reduction, against the oracle's
+    restatement (itself pinned by the reference-made golden) on square, non-square and history inputs."""
+    from oracle import vch2d_oracle as O2, vch1d_oracle as O1
+    F2 = V.module("Vch_control_2D.Forward2_solver")
+    F1 = V.module("Vch_control_1D.Forward_solver")
+    rng = np.random.default_rng(0)
+    for shp, hx, hy in (((9, 7), 0.1, 0.2), ((17, 17), 1 / 16, 1 / 16), ((33, 65), 0.03, 0.015)):
+        phi = rng.uniform(-0.999, 0.999, shp)
+        w = rng.standard_normal(shp)
+        for ww, eps in ((None, None), (w, 0.5e-2)):
+            ref = O2.free_energy(phi, 1e-4, 0.75, 1.0, hx, hy, w=ww, eps=eps)
+            assert abs(F2.free_energy(phi, 1e-4, 0.75, 1.0, hx, hy, w=ww, eps=eps) - ref) <= 1e-13 * max(1.0, abs(ref))
+    hist = rng.uniform(-0.9, 0.9, (5, 17, 17))
+    E = F2.free_energy_history(hist, 2e-4, 0.7, 1.1, 1 / 16, 1 / 16)
+    assert np.allclose(E, [O2.free_energy(h, 2e-4, 0.7, 1.1, 1 / 16, 1 / 16) for h in hist], rtol=1e-13)
+    g = golden("g2d_ops_16.npz")
+    assert abs(F2.free_energy(g["phi_old"], float(g["kappa"]), float(g["c1"]), float(g["c2"]), 1 / 16, 1 / 16, w=g["w_old"],
+                              eps=0.5e-2) - float(g["free_energy"])) < 1e-12 * max(1.0, abs(float(g["free_energy"])))
+    p1 = rng.uniform(-0.999, 0.999, (6, 41))
+    w1 = rng.standard_normal((6, 41))
+    E1 = F1.free_energy_history(p1, 9e-4, 0.75, 1.0, 1 / 40, w_hist=w1)
+    assert np.allclose(E1, [O1.free_energy(a, 9e-4, 0.75, 1.0, 1 / 40, w=b) for a, b in zip(p1, w1)], rtol=1e-13)
+    assert abs(F1.free_energy(p1[0], 9e-4, 0.75, 1.0, 1 / 40) - O1.free_energy(p1[0], 9e-4, 0.75, 1.0, 1 / 40)) < 1e-13
+    g1 = golden("g1d_ops_24.npz")
+    E24 = F1.free_energy(g1["phi_old"], float(g1["kappa"]), float(g1["c1"]), float(g1["c2"]), float(g1["Lx"]) / int(g1["N"]), w=g1["w_old"])
+    assert abs(E24 - float(g1["free_energy"])) < 1e-13 * max(1.0, abs(float(g1["free_energy"])))
+

@@ -67,7 +67,7 @@ def test_mass_conservation_and_energy_decrease(M2, default_run):
     w = np.outer(F.trapz_weights(129), F.trapz_weights(129))
     mass = np.array([np.sum(w * p) for p in phi_hist])
     assert np.abs(mass - mass[0]).max() <= 1e-11
-    E = [F.free_energy(p, cfg.kappa, cfg.c1, cfg.c2, 1 / 128, 1 / 128) for p in phi_hist]
+    E = F.free_energy_history(phi_hist, cfg.kappa, cfg.c1, cfg.c2, 1 / 128, 1 / 128)       # one device reduction
     assert np.all(np.diff(E) <= 1e-9), np.diff(E).max()
     assert E[-1] < E[0]
 
@@ -206,7 +206,7 @@ def test_1d_reference_invariants(V):
     ph, x, t = F.run_main_simulation(cfg, store_history=True, verbose=False)
     mass = ph @ (F.trapz_weights(129) / 128)
     assert np.abs(mass - mass[0]).max() <= 1e-12
-    E = [F.free_energy(p, cfg.kappa, cfg.c1, cfg.c2, 1 / 128) for p in ph]
+    E = F.free_energy_history(ph, cfg.kappa, cfg.c1, cfg.c2, 1 / 128)
     assert np.all(np.diff(E) <= 1e-9)
     base = 0.005
     run = lambda dt: F.run_main_simulation(K.ForwardSolverConfig(N=512, dt_initial=dt), store_history=True, verbose=False)[0][-1]   # default T, as T1f:267

@@ -76,7 +76,6 @@ def test_host_helpers_match_oracle(V):
     assert np.array_equal(F1.init_phi_random(50, 1e-2, amp=0.01, seed=5), O1.init_phi_random(50, 1e-2, amp=0.01, seed=5))
     phi = np.random.default_rng(0).uniform(-0.99, 0.99, (9, 7))
     assert np.array_equal(F2.regularized_log(phi, 1e-2), O2.reg_log(phi))
-    assert abs(F2.free_energy(phi, 1e-4, 0.75, 1.0, 0.1, 0.2) - O2.free_energy(phi, 1e-4, 0.75, 1.0, 0.1, 0.2)) < 1e-14
 
 
 def test_direction_generators_match_reference_goldens(V):

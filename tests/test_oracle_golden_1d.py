@@ -16,6 +16,8 @@ def test_operators():
     P = O1.Params1D(N=N, tau=float(g["tau"]), gamma=float(g["gamma"]), c1=float(g["c1"]),
                     c2=float(g["c2"]), kappa=float(g["kappa"]))
     assert relerr(O1.lap(g["v"], h), g["Lv"]) < TIGHT
+    Eg = float(g["free_energy"])
+    assert abs(O1.free_energy(g["phi_old"], P.kappa, P.c1, P.c2, h, w=g["w_old"]) - Eg) < 1e-13 * max(1.0, abs(Eg))
     assert relerr(O1.lap(O1.lap(g["v"], h), h), g["LLv"]) < TIGHT
     assert relerr(O1.lap_dense(N, h) @ g["v"], g["Lv"]) < TIGHT
     assert relerr(O1.mu_init(g["phi_old"], g["w_new"], P, h), g["mu0"]) < TIGHT
