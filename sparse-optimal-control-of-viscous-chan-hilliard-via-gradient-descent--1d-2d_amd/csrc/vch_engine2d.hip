@@ -453,7 +453,7 @@ static int schur_solve(vch2d_ctx *c, double dt, int budget) {
                         c->D_s, dt, c->x, zb[done & 1], pn, c->cg_v, c->part);
             }
             VCHCHK(precond(c, c->cg_v, 0, c->cg_q, 3, pn, c0, 0.0, 1.0, c2, 1));           // q = P^-1 A p, <p,q>_Z, <q,q>_Z
-            LAUNCH(k_fin_cg_step, dim3(c->B), dim3(64), c->st, c->gpart, c->gpart2, c->gnblk, c->part, c->nblk, done > 0 ? 1 : 0,
+            LAUNCH(k_fin_cg_step, dim3(c->B), dim3(192), c->st, c->gpart, c->gpart2, c->gnblk, c->part, c->nblk, done > 0 ? 1 : 0,
                    done & 1, c->lin_tol, c->lin_maxit);
         }
         if (done < budget) {

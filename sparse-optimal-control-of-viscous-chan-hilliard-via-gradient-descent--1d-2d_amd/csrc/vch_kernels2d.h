@@ -991,10 +991,21 @@ __global__ void k_fin_cg_step(TrajState *st, const double *__restrict__ gpart, c
     const int b = blockIdx.x;
     TrajState &S = st[b];
     if (!S.lin_active) return;
-    const double pq = fin_sum1(gpart, gnblk, b, 1, 0);
-    const double qq = fin_sum1(gpart2, gnblk, b, 1, 0);
-    const double gd = direct ? fin_sum1(part, nblk, b, NPART, 0) : 0.0;
+    // 192 threads: one wavefront per sum (each in the fixed order of fin_sum1), met in LDS
+    __shared__ double s3[3];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    {
+        const double *src = wv == 0 ? gpart : (wv == 1 ? gpart2 : part);
+        const int n = wv == 2 ? nblk : gnblk, stride = wv == 2 ? NPART : 1;
+        double a = 0.0;
+        if (wv < 2 || direct)
+            for (int t = lane; t < n; t += 64) a += src[((long)b * n + t) * stride];
+        a = wave_sum(a);
+        if (lane == 0) s3[wv] = a;
+    }
+    __syncthreads();
     if (threadIdx.x != 0) return;
+    const double pq = s3[0], qq = s3[1], gd = s3[2];
     const double gamma = direct ? gd : S.cg_gamma;
     S.cg_pending = 0;                        // the previous step went into x in k_schur_p
     if (!(pq > 0.0) || !(gamma > 0.0)) {     // round-off level residual: stop here
