@@ -20,7 +20,10 @@
 #pragma once
 #include "vch_common.h"
 
-constexpr int T1 = 256;                 // threads per trajectory workgroup
+#ifndef VCH_T1
+#define VCH_T1 512
+#endif
+constexpr int T1 = VCH_T1;              // threads per trajectory workgroup
 constexpr int NR_MAX = 1025;            // block rows kept in LDS
 constexpr double DSEP1 = 1e-2;          // F1:42
 
@@ -130,7 +133,9 @@ __device__ __forceinline__ Row row_at(const SysArgs &S, int i, int lvl) {
 // LDS image of the explicit rows: 14 arrays of NR_MAX doubles (A,B,C: 4 each; d: 2; x overwrites d)
 struct CrLds {
     double *v;      // base
-    __device__ __forceinline__ double &at(int comp, int m) { return v[comp * NR_MAX + m]; }
+    // rows are XOR-swizzled inside their block of 32: the cyclic-reduction levels address rows at strides
+    // 2, 4, ..., 1024, which un-swizzled fall on one or two LDS banks; (m >> 5) & 31 is 0 for m = 1024
+    __device__ __forceinline__ double &at(int comp, int m) { return v[comp * NR_MAX + (m ^ ((m >> 5) & 31))]; }
     __device__ __forceinline__ Row load(int m) {
         Row R;
         R.A = M2{at(0, m), at(1, m), at(2, m), at(3, m)};
