@@ -1334,3 +1334,28 @@ extern "C" int vch2d_prof_end(vch2d_ctx *c, double *ms_out, int64_t *count_out, 
 }
 
 extern "C" int vch2d_uses_fft(const vch2d_ctx *c) { return c ? (c->use_fft ? 1 : 0) : VCH_ERR_ARG; }
+
+#ifdef VCH_FFT_TIMING
+// tuning builds only: run ONE forward row pass on tmp[0] with phase stamps; out [B * blocks][4] ticks
+extern "C" int vch2d_debug_fft_phases(vch2d_ctx *c, long long *out, int cap) {
+    CTXCHK(c);
+    if (!c->use_fft || c->fax.logL != 10) return vch_fail(VCH_ERR_STATE, "debug: needs the 512-interval FFT path");
+    const int nblk = (c->G.ns + 1) / 2, n = c->B * nblk;
+    if (cap < n * 4) return vch_fail(VCH_ERR_ARG, "debug: buffer too small");
+    long long *dev = nullptr;
+    HIPCHK(hipMalloc((void **)&dev, sizeof(long long) * n * 4));
+    HIPCHK(hipMemset(dev, 0, sizeof(long long) * n * 4));
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_fft_dbg), &dev, sizeof(dev)));
+    SpecArgs sp{1.0, 0.0, 0.0, 0.0, c->ms, c->mf, nullptr, c->D_s, c->slot_stride, c->gpart, c->gpart2};
+    for (int rep = 0; rep < 3; ++rep)
+        LAUNCH((k_dct_rows<0, 1024, 10>), dim3(nblk, 1, c->B), dim3(FftThreads<1024>::T), c->G, c->fax, (const double *)c->tmp[0], 0L,
+               c->t1, 1.0, sp, c->st, 0);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out, dev, sizeof(long long) * n * 4, hipMemcpyDeviceToHost));
+    long long *nul = nullptr;
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_fft_dbg), &nul, sizeof(nul)));
+    hipFree(dev);
+    return n;
+}
+#endif
+

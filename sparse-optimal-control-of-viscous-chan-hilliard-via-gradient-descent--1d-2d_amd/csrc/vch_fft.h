@@ -27,6 +27,15 @@
 #include "vch_kernels2d.h"
 #include "vch_gemm.h"        // SpecArgs
 
+#ifdef VCH_FFT_TIMING
+// phase timing of the DCT kernels (tuning builds only, scripts/fft_phases.py): per workgroup
+// {start, after load, after FFT(s), end} in s_memrealtime ticks (100 MHz)
+__device__ long long *g_fft_dbg = nullptr;
+#define FFT_STAMP(i) do { if (g_fft_dbg && threadIdx.x == 0) g_fft_dbg[(((long)blockIdx.z * gridDim.x + blockIdx.x) * 4 + (i))] = wall_clock64(); } while (0)
+#else
+#define FFT_STAMP(i) do { } while (0)
+#endif
+
 struct FftAxis {
     int N, L, logL;          // intervals, FFT length 2N, log2 L
     const double2 *tw;       // exp(-2 pi i m / L), m = 0..L-1
@@ -164,6 +173,7 @@ __global__ __launch_bounds__(FftThreads<C>::T) void k_dct_rows(Geom G, FftAxis a
     const double *ib = in + b * G.plane + (in_slot_stride ? st[b].slot * in_slot_stride : 0);
     const int n1 = N + 1;
     const float inv_n1 = 1.0f / (float)n1;       // idx < 2^14: the float quotient is exact enough
+    FFT_STAMP(0);
     for (int idx = tid; idx < nfft * n1; idx += T) {
         const int f = nfft == 1 ? 0 : (int)(((float)idx + 0.5f) * inv_n1), j = idx - f * n1;
         const int ra = row0 + 2 * f, rb = ra + 1;
@@ -173,7 +183,9 @@ __global__ __launch_bounds__(FftThreads<C>::T) void k_dct_rows(Geom G, FftAxis a
         if (j > 0 && j < N) buf[PADC(f * L + L - j)] = v;
     }
     __syncthreads();
+    FFT_STAMP(1);
     fft_lds<C, LOGL>(buf, ax);
+    FFT_STAMP(2);
     double dot = 0.0, dot2 = 0.0, dbar = 0.0;
     const double *Dp = nullptr, *Ob = nullptr;
     if (EPI == 3) {
@@ -197,6 +209,7 @@ __global__ __launch_bounds__(FftThreads<C>::T) void k_dct_rows(Geom G, FftAxis a
             }
         }
     }
+    FFT_STAMP(3);
     if (EPI == 3) {
         dot = wave_sum(dot);
         dot2 = wave_sum(dot2);
