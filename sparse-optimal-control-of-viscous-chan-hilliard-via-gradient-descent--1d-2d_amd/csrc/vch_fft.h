@@ -46,13 +46,22 @@ __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
     return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
-// Optional padding of the LDS image by one complex per four (index c -> c + c/4): the first
-// radix-4 pass stores with a 64-byte lane stride (4-way ds_write_b128 bank conflict unpadded).
+// LDS image addressing.  A wavefront's ds_*_b128 is served 8 lanes (one 128-byte row of banks) per clock.
+// Reads of every pass take consecutive complex numbers (conflict-free); the Stockham writes of the first two
+// radix-4 passes do not: lane j writes index 4j + r (pass 0: 8 lanes fall on 2 of the 8 slots of a row) and
+// 16 (j >> 2) + (j & 3) + 4r (pass 1: 4 of 8).  XOR-ing the slot (index bits 0..2) with (i3, i4, i4) makes
+// both patterns -- and still every aligned run of 8 consecutive indices -- hit 8 distinct slots.
+// FFT_SWZ=0 restores the plain image, FFT_PAD=1 the padded one (profiles/r01_c_fft_variants.txt).
 #ifndef FFT_PAD
 #define FFT_PAD 0
 #endif
+#ifndef FFT_SWZ
+#define FFT_SWZ 1
+#endif
 #if FFT_PAD
 #define PADC(c) ((c) + ((c) >> 2))
+#elif FFT_SWZ
+#define PADC(c) ((c) ^ ((((c) >> 3) & 1) | ((((c) >> 4) & 1) * 6)))
 #else
 #define PADC(c) (c)
 #endif
