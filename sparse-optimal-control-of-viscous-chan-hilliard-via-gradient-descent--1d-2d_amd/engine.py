@@ -63,7 +63,7 @@ class Engine2D:
         self.shape = (self.Nx + 1, self.Ny + 1)
         self.ctx = self.lib.vch2d_create(C.byref(self.p), self.B, self.max_steps, self.device)
         if not self.ctx:
-            raise VchError("vch2d_create failed: " + _lib.last_error())
+            raise ValueError("vch2d_create failed: " + _lib.last_error())
         self.uses_fft = bool(self.lib.vch2d_uses_fft(self.ctx))
         self.x = np.linspace(0.0, float(Lx), self.Nx + 1)
         self.y = np.linspace(0.0, float(Ly), self.Ny + 1)
