@@ -143,31 +143,52 @@ def main():
         phi0[k * Bc:(k + 1) * Bc], np.broadcast_to(phi_T, (Bc,) + phi_T.shape).copy(), t_hist, opt, ramp=True, T=T)))
     t_init = time.perf_counter() - t_init
 
-    def pgd_step():
-        rs = on_all(lambda k, e: e.pgd_iterate(1))
-        r = dict(cost=np.concatenate([x["cost"] for x in rs]), attempts=np.concatenate([x["attempts"] for x in rs]),
-                 seconds={k: max(x["seconds"][k] for x in rs) for k in rs[0]["seconds"]})
-        return r
+    import queue
+    import threading
 
-    def step_costs(r):
-        """[B][5] costs of this rank after an iteration: total from the engine, parts not needed"""
-        J = np.zeros((B, 5))
-        J[:, 4] = r["cost"][:, 0]
-        return J
+    def run_iterations(n):
+        """n PGD iterations of every context.  The trajectories of different contexts are independent
+        problems, so each context advances at its own pace (one worker thread each; a line search that
+        ends early in one context does not wait for the other); the main thread takes the costs of
+        iteration k from every context as they arrive and issues the k-th all-reduce -- one RCCL
+        collective per iteration, in iteration order, none of them on a context's critical path."""
+        qs = [queue.Queue() for _ in engs]
+
+        def worker(k):
+            try:
+                for _ in range(n):
+                    qs[k].put(engs[k].pgd_iterate(1))
+            except BaseException as exc:          # surfaces in the main thread
+                qs[k].put(exc)
+
+        ths = [threading.Thread(target=worker, args=(k,), daemon=True) for k in range(K)]
+        for th in ths:
+            th.start()
+        outs = []
+        for _ in range(n):
+            rs = [q.get() for q in qs]
+            for r in rs:
+                if isinstance(r, BaseException):
+                    raise r
+            J = np.zeros((B, 5))
+            J[:, 4] = np.concatenate([x["cost"] for x in rs])[:, 0]
+            Jsum = par.allreduce_cost(J, dist, dev)      # the single RCCL collective of an iteration
+            outs.append(dict(cost_sum=float(Jsum[4]), attempts=int(sum(int(x["attempts"].sum()) for x in rs)),
+                             seconds={kk: max(x["seconds"][kk] for x in rs) for kk in rs[0]["seconds"]}))
+        for th in ths:
+            th.join()
+        return outs
 
     costs = []
-    for _ in range(a.warmup):
-        r = pgd_step()
-        par.allreduce_cost(step_costs(r), dist, dev)
+    if a.warmup:
+        run_iterations(a.warmup)
     par.barrier(dist, dev)
     t0 = time.perf_counter()
     buckets = {}
     attempts = 0
-    for _ in range(a.steps):
-        r = pgd_step()                          # synchronous: returns when the device is done
-        Jsum = par.allreduce_cost(step_costs(r), dist, dev)      # the single RCCL collective of an iteration
-        costs.append(float(Jsum[4]))
-        attempts += int(r["attempts"].sum())
+    for r in run_iterations(a.steps):               # synchronous: returns when the devices are done
+        costs.append(r["cost_sum"])
+        attempts += r["attempts"]
         for k, v in r["seconds"].items():
             buckets[k] = buckets.get(k, 0.0) + float(v)
     par.barrier(dist, dev)
