@@ -169,6 +169,33 @@ def test_newton_batch_divergent_control_flow(V):
     assert relerr(pn[0], g["phi_new_dt1e-3"]) < SOLVE and relerr(pn[1], g["phi_new_stress"]) < SOLVE
 
 
+def test_linear_solve_degenerate_right_hand_sides(V, O2):
+    """Corner cases of the single-reduction CG in one batch: a zero right-hand side (x = 0, no iteration),
+    a constant field (constant Jacobian diagonal: P differs from A by a multiple of M only, a handful of
+    iterations, the predicted <z,z> collapsing to round-off) and a generic field, each against the
+    oracle's direct solve."""
+    N, dt = 16, 1e-2
+    rng = np.random.default_rng(11)
+    P = O2.Params2D(Nx=N, Ny=N)
+    h = 1.0 / N
+    phi = np.stack([rng.uniform(-0.9, 0.9, (N + 1, N + 1)), np.full((N + 1, N + 1), 0.3), rng.uniform(-0.5, 0.5, (N + 1, N + 1))])
+    a = rng.standard_normal((3, N + 1, N + 1))
+    b = rng.standard_normal((3, N + 1, N + 1))
+    a[0] = 0.0
+    b[0] = 0.0
+    e = V.Engine2D(Nx=N, Ny=N, batch=3)
+    dphi, dmu, st = e.jacobian_solve(phi, dt, a, b)
+    assert not dphi[0].any() and not dmu[0].any()
+    L = O2.lap_matrix(N, N, h, h)
+    for k in (1, 2):
+        J = O2.jac_matrix(phi[k], dt, P, L)
+        from scipy.sparse.linalg import spsolve
+        ref = spsolve(J.tocsc(), np.concatenate([a[k].ravel(), b[k].ravel()]))
+        n = (N + 1) ** 2
+        assert relerr(dphi[k].ravel(), ref[:n]) < SOLVE and relerr(dmu[k].ravel(), ref[n:]) < SOLVE, (k, st)
+    assert st["max_lin_relres"] <= 1e-14
+
+
 # ---------------------------------------------------------------------------------------
 # forward march, adjoint sweep, cost, prox
 # ---------------------------------------------------------------------------------------
