@@ -12,7 +12,7 @@ from ..engine import make_opt
 from .Forward_solver import run_main_simulation
 from .backward_solver import run_backward
 from .cost_and_function import calculate_cost, calculate_gradient, perform_gradient_step
-from .config import ForwardSolverConfig, OptimizationConfig
+from .config import ForwardSolverConfig, OptimizationConfig, load_params, save_params
 from ._ctx import engine_for
 
 INTERACTIVE = False
@@ -165,4 +165,35 @@ def run_optimization_resident(fwd_config: ForwardSolverConfig, opt_config: Optim
     finally:
         eng.close()
     return out
+
+
+def main(n_iter=None, params_file="last_run_config.json", control_file="optimal_control.npy", num_directions=3,
+         verbose=True):
+    """Non-interactive equivalent of the reference's `__main__` block (G1:256-609) without prompts and
+    plots: parameters from the last-run JSON (defaults if absent), the PGD loop (device-resident), the
+    final adjoint, `optimal_control.npy` (G1:487), the coercivity finite-difference test (G1:490-509), the
+    sparsity statistic (G1:518) and `save_params` (G1:608)."""
+    from .second_order_conditions import approximate_second_order_condition
+    say = print if verbose else (lambda *a, **k: None)
+    allp = load_params(params_file)
+    fwd, opt = allp.forward_solver, allp.optimization
+    res = run_optimization_resident(fwd, opt, n_iter=n_iter)
+    it = int(res["iters"])
+    costs = np.asarray(res["costs"])
+    say(f"Completed Iterations: {it}\nFinal Cost: {costs[it]:.5f}\nCost Reduction: {100 * (1 - costs[it] / costs[0]):.2f}%")
+    x, t_hist = res["x"], res["t_hist"]
+    _, _, r_opt = run_backward(res["phi"], x, t_hist, opt.b1, opt.b2, res["phi_Q"], res["phi_T"])
+    np.save(control_file, res["u"])
+    say(f"Optimal control saved as '{control_file}'")
+    sink = contextlib.nullcontext() if verbose else contextlib.redirect_stdout(io.StringIO())
+    with sink:
+        hv = approximate_second_order_condition(fwd_config=fwd, u_star=res["u"], r_star=r_opt, phi_star=res["phi"], x=x,
+                                                t_hist=t_hist, b1=opt.b1, b2=opt.b2, b3=opt.b3, kappa=opt.kappa_sparsity,
+                                                phi_Q_target=res["phi_Q"], phi_T_target=res["phi_T"], u_min=opt.u_min,
+                                                u_max=opt.u_max, num_directions=num_directions, epsilon=1e-4, seed=42)
+        for i, d2 in enumerate(hv, start=1):
+            say(f"  Direction {i}: estimated second derivative = {d2:.6e}")
+        sp = verify_sparsity_condition(res["u"], r_opt, opt.kappa_sparsity, verbose=verbose)
+    save_params(fwd, opt, it, params_file)
+    return dict(res, hessian_values=hv, sparsity=sp, r_optimal=r_opt)
 

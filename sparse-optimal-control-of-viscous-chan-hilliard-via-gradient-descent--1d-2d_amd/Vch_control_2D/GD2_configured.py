@@ -16,7 +16,7 @@ from ._ctx import engine_for_config
 from .Forward2_solver import run_main_simulation, init_phi_random, DELTA_SEP
 from .backward2_solver import run_backward                                   # noqa: F401
 from .cost2_and_function import calculate_cost, calculate_gradient, proximal_step   # noqa: F401
-from .config import ForwardSolverConfig, OptimizationConfig
+from .config import ForwardSolverConfig, OptimizationConfig, load_params, save_params
 
 INTERACTIVE = False
 DEFAULT_TARGET_CHOICE = 1
@@ -78,3 +78,55 @@ def run_optimization(fwd_config: ForwardSolverConfig, opt_config: OptimizationCo
     return dict(costs=costs, alphas=res["alpha"], attempts=res["attempts"], changes=res["change"],
                 iters=res["iters"], seconds=res["seconds"], u=eng.pgd_get("u"), phi=eng.pgd_get("phi"),
                 r=eng.pgd_get("r"), phi_T=phi_T, t_hist=t_hist, x=eng.x.copy(), y=eng.y.copy())
+
+
+def main(n_iter=None, params_file="last_run_config_2d.json", num_directions=5, verbose=True):
+    """Non-interactive equivalent of the reference's `__main__` block (G2:230-441) without previews and
+    plots: parameters from the last-run JSON (defaults if absent, K2:181-190), uncontrolled march, targets
+    (choice 1/1), the PGD loop (device-resident), the time-study summary (G2:403-416), the final adjoint,
+    the coercivity finite-difference test and the sparsity statistic (G2:424-437), `save_params`
+    (G2:440).  Returns the run_optimization dict extended by `hessian_values` and `sparsity`."""
+    from .second_order_conditions_2d import approximate_second_order_condition_2d, verify_sparsity_condition
+    say = print if verbose else (lambda *a, **k: None)
+    allp = load_params(params_file)
+    fwd, opt = allp.forward_solver, allp.optimization
+    say("=" * 60 + "\n    2D GRADIENT DESCENT OPTIMIZATION \n" + "=" * 60)
+    say("Forward Solver Config:\n" + fwd.model_dump_json(indent=2) + "\nOptimization Config:\n" + opt.model_dump_json(indent=2))
+    t0 = time.time()
+    res = run_optimization(fwd, opt, n_iter=n_iter)
+    B = res["costs"].shape[0]
+    assert B == 1
+    costs = res["costs"][0]
+    it = int(res["iters"])
+    say(f"Completed Iterations: {it}\nFinal Cost: {costs[it]:.5f}\nCost Reduction: {100 * (1 - costs[it] / costs[0]):.2f}%")
+    sec = res["seconds"]
+    say("\n" + "=" * 50 + "\n  TIME STUDY SUMMARY\n" + "=" * 50)
+    say(f"Total backward-solve time:        {sec['backward']:.3f}s")
+    say(f"Total optimistic forward time:    {sec['optimistic_forward']:.3f}s")
+    say(f"Total optimistic cost time:       {sec['cost']:.3f}s")
+    say(f"Total backtracking time:          {sec['backtracking']:.3f}s  (attempts={int(res['attempts'].sum())})")
+    ok = res["attempts"][0, :it] == 0
+    if ok.any():
+        say(f"ALPHA ADVISOR: a good initial alpha_max for the next run is {float(np.mean(res['alphas'][0, :it][ok])):.4f}")
+    x, y, t_hist = res["x"], res["y"], res["t_hist"]
+    phi_T, phi_Q = build_targets(x, y, t_hist, res["phi"][0], fwd.Lx, fwd.Ly, fwd.T, choice_t=DEFAULT_TARGET_CHOICE,
+                                 choice_q=DEFAULT_TRACKING_CHOICE)
+    out = dict(res, hessian_values=None, sparsity=None, runtime_s=None)
+    try:
+        _, _, r_opt = run_backward(res["phi"], x, y, t_hist, fwd, opt.b1, opt.b2, phi_Q, phi_T)
+        sink = contextlib.nullcontext() if verbose else contextlib.redirect_stdout(io.StringIO())
+        with sink:
+            hv = approximate_second_order_condition_2d(
+                u_star=res["u"], r_star=r_opt, phi_star=res["phi"], x=x, y=y, t_hist=t_hist, b1=opt.b1, b2=opt.b2, b3=opt.b3,
+                kappa=opt.kappa_sparsity, phi_Q_target=phi_Q, phi_T_target=phi_T, u_min=opt.u_min, u_max=opt.u_max,
+                num_directions=num_directions, epsilon=1e-4, seed=42, fwd_config=fwd)
+            say("Coercivity condition appears to hold in tested directions." if all(v > 0 for v in hv)
+                else "Coercivity condition may fail; non-positive second derivatives found.")
+            out["sparsity"] = verify_sparsity_condition(res["u"], r_opt, opt.kappa_sparsity)
+        out["hessian_values"] = hv
+    except Exception as e:          # G2:438-439
+        say(f"[Warning] Could not perform final analysis (second-order/sparsity): {e}")
+    save_params(fwd, opt, it, params_file)
+    out["runtime_s"] = time.time() - t0
+    return out
+

@@ -173,3 +173,32 @@ def test_free_energy_device_reduction(V):
     E24 = F1.free_energy(g1["phi_old"], float(g1["kappa"]), float(g1["c1"]), float(g1["c2"]), float(g1["Lx"]) / int(g1["N"]), w=g1["w_old"])
     assert abs(E24 - float(g1["free_energy"])) < 1e-13 * max(1.0, abs(float(g1["free_energy"])))
 
+
+
+def test_driver_mains_roundtrip(V, tmp_path):
+    """the non-interactive `main()` of both drivers -- parameters from the last-run
+    JSON, PGD loop, final adjoint, coercivity test, sparsity statistic, `save_params`, and (1D)
+    `optimal_control.npy` -- reproduce the reference-made PGD goldens and write the reference's files."""
+    import json
+    K2 = V.module("Vch_control_2D.config")
+    G2 = V.module("Vch_control_2D.GD2_configured")
+    K1 = V.module("Vch_control_1D.config")
+    G1 = V.module("Vch_control_1D.GD_1D")
+    gp = golden("g2d_pgd_16.npz")
+    f2 = str(tmp_path / "last_run_config_2d.json")
+    K2.save_params(K2.ForwardSolverConfig(Nx=16, Ny=16, T=float(gp["T"]), dt_initial=float(gp["dt"])),
+                   K2.OptimizationConfig(alpha_max=float(gp["alpha_max"])), 0, f2)
+    out = G2.main(n_iter=int(gp["n_iter"]), params_file=f2, num_directions=2, verbose=False)
+    assert np.allclose(out["costs"][0], gp["costs"], rtol=1e-9) and relerr(out["u"], gp["u_final"]) < 1e-8
+    assert len(out["hessian_values"]) == 2 and all(np.isfinite(out["hessian_values"])) and 0 <= out["sparsity"][2] <= 100
+    saved = json.load(open(f2))
+    assert saved["last_run_iterations"] == int(gp["n_iter"]) and saved["forward_solver"]["Nx"] == 16
+    assert K2.load_params(f2).optimization.alpha_max == float(gp["alpha_max"])
+    g1 = golden("g1d_pgd_32.npz")
+    f1, fu = str(tmp_path / "last_run_config.json"), str(tmp_path / "optimal_control.npy")
+    K1.save_params(K1.ForwardSolverConfig(N=int(g1["N"]), T=float(g1["T"]), dt_initial=float(g1["dt"])),
+                   K1.OptimizationConfig(alpha_max=float(g1["alpha_max"])), 0, f1)
+    o1 = G1.main(n_iter=int(g1["n_iter"]), params_file=f1, control_file=fu, num_directions=2, verbose=False)
+    assert np.allclose(o1["costs"], g1["costs"], rtol=1e-9)
+    assert relerr(np.load(fu), g1["u_final"]) < 1e-8 and relerr(o1["r_optimal"], golden("g1d_soc_32.npz")["r_opt"]) < 1e-8
+    assert len(o1["hessian_values"]) == 2 and json.load(open(f1))["last_run_iterations"] == int(g1["n_iter"])
