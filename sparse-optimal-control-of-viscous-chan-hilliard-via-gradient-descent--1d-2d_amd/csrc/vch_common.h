@@ -24,9 +24,11 @@ static inline int vch_fail(int code, const char *fmt, ...) {
 #define HIPCHK(call)                                                                        \
     do {                                                                                    \
         hipError_t e_ = (call);                                                             \
-        if (e_ != hipSuccess)                                                               \
+        if (e_ != hipSuccess) {                                                             \
+            (void)hipGetLastError();     /* reset the sticky error for later launch checks */ \
             return vch_fail(VCH_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
                             __FILE__, __LINE__);                                            \
+        }                                                                                   \
     } while (0)
 #define VCHCHK(call)                   \
     do {                               \

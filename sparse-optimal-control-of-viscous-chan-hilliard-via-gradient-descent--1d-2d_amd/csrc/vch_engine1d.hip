@@ -95,6 +95,7 @@ extern "C" vch1d_ctx *vch1d_create(const vch1d_params *p, int batch, int max_ste
         return nullptr;
     }
     if (hipSetDevice(device) != hipSuccess) {
+        (void)hipGetLastError();          // do not leave the sticky error for the next launch check
         vch_fail(VCH_ERR_HIP, "hipSetDevice(%d) failed", device);
         return nullptr;
     }

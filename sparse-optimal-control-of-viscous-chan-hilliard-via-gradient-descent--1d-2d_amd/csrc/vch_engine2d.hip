@@ -192,6 +192,7 @@ extern "C" vch2d_ctx *vch2d_create(const vch2d_params *p, int batch, int max_ste
         return nullptr;
     }
     if (hipSetDevice(device) != hipSuccess) {
+        (void)hipGetLastError();          // do not leave the sticky error for the next launch check
         vch_fail(VCH_ERR_HIP, "hipSetDevice(%d) failed", device);
         return nullptr;
     }
@@ -444,23 +445,28 @@ static int schur_solve(vch2d_ctx *c, double dt, int budget) {
         const int chunk = std::min(budget - done, CG_CHUNK);
         for (int j = 0; j < chunk; ++j, ++done) {
             double *pn = c->cg_p[done & 1], *po = c->cg_p[(done + 1) & 1];
-            // the step of iteration done-1 goes into x and z on the way (see k_schur_p)
+            // iteration `done`: the reduction point of iteration done-1 is resolved inside the kernel and its
+            // step goes into x and z on the way (see k_schur_p); 4 launches per iteration
             if (done == 0) {
                 LAUNCHC(PC_SCHUR_P, (k_schur_p<1>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, zb[0], c->cg_q, po, c->D_s, dt,
-                        c->x, zb[1], pn, c->cg_v, c->part);
+                        c->x, zb[1], pn, c->cg_v, c->part, (const double *)c->gpart, (const double *)c->gpart2, c->gnblk, 0,
+                        c->lin_tol, c->lin_maxit);
             } else {
                 LAUNCHC(PC_SCHUR_P, (k_schur_p<0>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, zb[(done + 1) & 1], c->cg_q, po,
-                        c->D_s, dt, c->x, zb[done & 1], pn, c->cg_v, c->part);
+                        c->D_s, dt, c->x, zb[done & 1], pn, c->cg_v, c->part, (const double *)c->gpart, (const double *)c->gpart2,
+                        c->gnblk, done, c->lin_tol, c->lin_maxit);
             }
-            VCHCHK(precond(c, c->cg_v, 0, c->cg_q, 3, pn, c0, 0.0, 1.0, c2, 1));           // q = P^-1 A p, <p,q>_Z, <q,q>_Z
-            LAUNCH(k_fin_cg_step, dim3(c->B), dim3(192), c->st, c->gpart, c->gpart2, c->gnblk, c->part, c->nblk, done > 0 ? 1 : 0,
-                   done & 1, c->lin_tol, c->lin_maxit);
+            VCHCHK(precond(c, c->cg_v, 0, c->cg_q, 3, pn, c0, 0.0, 1.0, c2, 2 + (done & 1)));   // q = P^-1 A p, <p,q>_Z, <q,q>_Z
         }
         if (done < budget) {
+            LAUNCH(k_cg_publish, dim3((c->B + 63) / 64), dim3(64), c->st, (done - 1) & 1, c->B);
             VCHCHK(sync_state(c));
             if (!any_lin_active(c)) break;
         }
     }
+    // the reduction point of the last enqueued iteration, then its step
+    LAUNCH(k_fin_cg_step, dim3(c->B), dim3(192), c->st, c->gpart, c->gpart2, c->gnblk, c->part, c->nblk, (done - 1) & 1,
+           done - 1 >= 1 ? 1 : 0, (done - 1) & 1, (done - 1) & 1, c->lin_tol, c->lin_maxit);
     LAUNCHC(PC_CG_UPDATE, k_cg_finish, c->grid, dim3(NTH), c->G, c->st, c->cg_p[0], c->cg_p[1], c->x);
     return 0;
 }

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(FftThreads<C>::T) void k_dct_rows(Geom G, FftAxis a
                                                   long in_slot_stride, double *__restrict__ out, double scale,
                                                   SpecArgs sp, const TrajState *__restrict__ st, int gate) {
     const int b = blockIdx.z;
-    if (gate && !st[b].lin_active) return;
+    if (gate && !gate_open(st[b], gate)) return;
     __shared__ double2 buf[FftLds<C>::SIZE];
     constexpr int T = FftThreads<C>::T;
     const int tid = threadIdx.x;
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(FftThreads<C>::T) void k_dct_cols(Geom G, FftAxis a
                                                   double *__restrict__ out, double scale, SpecArgs sp,
                                                   const TrajState *__restrict__ st, int gate) {
     const int b = blockIdx.z;
-    if (gate && !st[b].lin_active) return;
+    if (gate && !gate_open(st[b], gate)) return;
     __shared__ double2 buf[FftLds<C>::SIZE];
     constexpr int T = FftThreads<C>::T;
     const int tid = threadIdx.x;

@@ -40,14 +40,14 @@ struct SpecArgs {           // multiplier = 1 / (c0 + m (c1a + c1b*dbar[b] + c2 
 
 // EPI: 0 store, 1 store * spectral multiplier, 2 accumulate (C += A B), 3 store + weighted dot partial
 // A_KMAJOR: A is stored [K][M] (lda = row length M-side), else [M][K].
-// gate: 0 none, 1 only trajectories with lin_active
+// gate: 0 none, 1 only trajectories with lin_active, 2 / 3 with ci_active[0] / [1] (gate_open)
 template <bool A_KMAJOR, int EPI>
 __global__ __launch_bounds__(256) void k_gemm(int M, int N, int K, const double *__restrict__ A, long lda,
                                                long sA, long a_slot_stride, const double *__restrict__ Bm,
                                                long ldb, long sB, double *__restrict__ C, long ldc, long sC,
                                                SpecArgs sp, const TrajState *__restrict__ st, int gate) {
     const int b = blockIdx.z;
-    if (gate && !st[b].lin_active) return;
+    if (gate && !gate_open(st[b], gate)) return;
     __shared__ double As[GK * LDK];     // 1280 doubles; the [i][k] image needs 64*17 = 1088
     __shared__ double Bs[GK * LDK];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;

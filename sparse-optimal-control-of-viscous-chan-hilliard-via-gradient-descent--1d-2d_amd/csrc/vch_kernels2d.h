@@ -40,11 +40,21 @@ struct TrajState {
     double cg_gamma, cg_gamma0, cg_alpha, cg_beta;
     int lin_budget;            // rigorous iteration bound from the spectrum of P^-1 A
     int cg_pending, cg_pbuf, cg_pad;   // forward CG: step (alpha, p[cg_pbuf]) computed but not yet added to x
+    // forward CG, per-iteration state in two copies: iteration k's stencil kernel derives the step of
+    // iteration k-1 itself (every workgroup, redundantly), reading copy (k-1)&1 while one workgroup
+    // writes copy k&1 -- no workgroup ever reads a field that another one writes in the same launch
+    int ci_active[2], ci_it[2];
+    double ci_gamma[2];
     // mass fix (F2:565-577)
     double mass0, mass_err, Wint;
     // scratch for cost / change norms
     double aux[4];
 };
+
+// gate codes of the preconditioner kernels: 1 = lin_active, 2 / 3 = copy 0 / 1 of the forward CG's per-iteration flag
+__device__ __forceinline__ bool gate_open(const TrajState &S, int gate) {
+    return gate == 1 ? S.lin_active != 0 : S.ci_active[gate - 2] != 0;
+}
 
 struct Phys {
     double tau, gamma, c1, c2, kappa;
@@ -971,7 +981,10 @@ __device__ __forceinline__ double fin_sum1(const double *part, int n, int b, int
 __global__ void k_fin_cg_init(TrajState *st, const double *__restrict__ gpart, int gnblk) {
     const int b = blockIdx.x;
     TrajState &S = st[b];
-    if (threadIdx.x == 0) S.cg_pending = 0;
+    if (threadIdx.x == 0) {
+        S.cg_pending = 0;
+        if (!S.lin_active) S.ci_active[0] = 0;
+    }
     if (!S.lin_active) return;
     double g = fin_sum1(gpart, gnblk, b, 1, 0);
     if (threadIdx.x != 0) return;
@@ -980,22 +993,49 @@ __global__ void k_fin_cg_init(TrajState *st, const double *__restrict__ gpart, i
     S.lin_it = 0;
     S.lin_rel = 1.0;
     if (!(g > 0.0)) S.lin_active = 0;        // zero right-hand side: x = 0 is the solution
+    S.ci_active[0] = S.lin_active;
+    S.ci_it[0] = 0;
+    S.ci_gamma[0] = g;
 }
 
-// Forward CG, the one reduction point of an iteration (see the header of the CG section).
-//   gpart / gpart2: partials of <p,q>_Z and <q,q>_Z from the preconditioner epilogue;
-//   part[.,0]: partial of <z,z>_Z from k_schur_p (direct != 0), else gamma is the stored one.
-__global__ void k_fin_cg_step(TrajState *st, const double *__restrict__ gpart, const double *__restrict__ gpart2,
-                              int gnblk, const double *__restrict__ part, int nblk, int direct, int pbuf,
-                              double tol, int maxit) {
-    const int b = blockIdx.x;
-    TrajState &S = st[b];
-    if (!S.lin_active) return;
-    // 192 threads: one wavefront per sum (each in the fixed order of fin_sum1), met in LDS
-    __shared__ double s3[3];
+// Forward CG, the scalar step of one iteration from the three sums of its reduction point
+// (see the header of the CG section).
+struct CgNext {
+    int active, breakdown, it;
+    double alpha, beta, gamma, rel;
+};
+__device__ __forceinline__ CgNext cg_next(double pq, double qq, double gamma, double gamma0, int it_old, double tol,
+                                          int maxit) {
+    CgNext n;
+    n.it = it_old;
+    if (!(pq > 0.0) || !(gamma > 0.0)) {     // round-off level residual: stop here, no step
+        n.active = 0; n.breakdown = 1; n.alpha = 0.0; n.beta = 0.0; n.gamma = fmax(gamma, 0.0);
+        n.rel = gamma0 > 0.0 ? sqrt(fmax(gamma, 0.0) / gamma0) : 0.0;
+        return n;
+    }
+    n.breakdown = 0;
+    n.alpha = gamma / pq;
+    double gn = n.alpha * n.alpha * qq - gamma;
+    if (gn > 1e-13 * gamma) {
+        n.beta = gn / gamma;
+    } else {                                  // prediction lost in cancellation: restart the direction
+        gn = 1e-13 * gamma;
+        n.beta = 0.0;
+    }
+    n.gamma = gn;
+    n.it = it_old + 1;
+    n.rel = sqrt(gn / gamma0);
+    n.active = (n.rel > tol && n.it < maxit) ? 1 : 0;
+    return n;
+}
+
+// the three sums, one wavefront each (fixed order); all threads of the workgroup call it (>= 192 threads)
+__device__ __forceinline__ void cg_sums(const double *__restrict__ gpart, const double *__restrict__ gpart2, int gnblk,
+                                        const double *__restrict__ part, int nblk, int pslot, int direct, int b,
+                                        double *s3 /* LDS [3] */) {
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    {
-        const double *src = wv == 0 ? gpart : (wv == 1 ? gpart2 : part);
+    if (wv < 3) {
+        const double *src = wv == 0 ? gpart : (wv == 1 ? gpart2 : part + pslot);
         const int n = wv == 2 ? nblk : gnblk, stride = wv == 2 ? NPART : 1;
         double a = 0.0;
         if (wv < 2 || direct)
@@ -1004,38 +1044,51 @@ __global__ void k_fin_cg_step(TrajState *st, const double *__restrict__ gpart, c
         if (lane == 0) s3[wv] = a;
     }
     __syncthreads();
-    if (threadIdx.x != 0) return;
-    const double pq = s3[0], qq = s3[1], gd = s3[2];
-    const double gamma = direct ? gd : S.cg_gamma;
-    S.cg_pending = 0;                        // the previous step went into x in k_schur_p
-    if (!(pq > 0.0) || !(gamma > 0.0)) {     // round-off level residual: stop here
-        S.lin_active = 0;
-        S.cg_alpha = 0.0;
-        S.lin_rel = S.cg_gamma0 > 0.0 ? sqrt(fmax(gamma, 0.0) / S.cg_gamma0) : 0.0;
-        if (S.lin_rel > S.lin_maxrel) S.lin_maxrel = S.lin_rel;
+}
+
+// record the step in the trajectory's state (one thread); wr = copy of the per-iteration state to write
+__device__ __forceinline__ void cg_record(TrajState &S, const CgNext &n, int wr) {
+    S.cg_alpha = n.alpha;
+    S.cg_beta = n.beta;
+    S.cg_gamma = n.gamma;
+    S.lin_rel = n.rel;
+    if (!n.breakdown) {
+        S.lin_it = n.it;
+        S.lin_total++;
+    }
+    if (!n.active && n.rel > S.lin_maxrel) S.lin_maxrel = n.rel;
+    S.ci_active[wr] = n.active;
+    S.ci_it[wr] = n.it;
+    S.ci_gamma[wr] = n.gamma;
+}
+
+// The reduction point of the LAST enqueued iteration (the earlier ones are resolved inside the next
+// k_schur_p): reads copy rd of the per-iteration state, leaves the step pending for k_cg_finish and
+// publishes lin_active for the kernels and the host code outside the CG loop.
+__global__ void k_fin_cg_step(TrajState *st, const double *__restrict__ gpart, const double *__restrict__ gpart2,
+                              int gnblk, const double *__restrict__ part, int nblk, int pslot, int direct, int pbuf,
+                              int rd, double tol, int maxit) {
+    const int b = blockIdx.x;
+    TrajState &S = st[b];
+    __shared__ double s3[3];
+    if (!S.lin_active) return;
+    if (!S.ci_active[rd]) {                  // converged earlier: its last step is already in x
+        if (threadIdx.x == 0) { S.lin_active = 0; S.cg_pending = 0; }
         return;
     }
-    const double alpha = gamma / pq;
-    double gn = alpha * alpha * qq - gamma;
-    double beta;
-    if (gn > 1e-13 * gamma) {
-        beta = gn / gamma;
-    } else {                                  // prediction lost in cancellation: restart the direction
-        gn = 1e-13 * gamma;
-        beta = 0.0;
-    }
-    S.cg_alpha = alpha;
-    S.cg_beta = beta;
-    S.cg_gamma = gn;
-    S.cg_pending = 1;
+    cg_sums(gpart, gpart2, gnblk, part, nblk, pslot, direct, b, s3);
+    if (threadIdx.x != 0) return;
+    const CgNext n = cg_next(s3[0], s3[1], direct ? s3[2] : S.ci_gamma[rd], S.cg_gamma0, S.ci_it[rd], tol, maxit);
+    cg_record(S, n, rd ^ 1);
+    S.cg_pending = n.breakdown ? 0 : 1;
     S.cg_pbuf = pbuf;
-    S.lin_it++;
-    S.lin_total++;
-    S.lin_rel = sqrt(gn / S.cg_gamma0);
-    if (!(S.lin_rel > tol) || S.lin_it >= maxit) {
-        S.lin_active = 0;
-        if (S.lin_rel > S.lin_maxrel) S.lin_maxrel = S.lin_rel;
-    }
+    S.lin_active = n.active;
+}
+
+// lin_active <- copy rd of the per-iteration state (before the host looks at the state inside a long solve)
+__global__ void k_cg_publish(TrajState *st, int rd, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B && st[b].lin_active && !st[b].ci_active[rd]) st[b].lin_active = 0;
 }
 
 // alpha = gamma / <p, q>_Z ; src 0: GEMM partials (1 value), src 1: stencil partials (slot k)
@@ -1261,7 +1314,7 @@ __global__ __launch_bounds__(NTH) void k_ramp(Geom G, int tiles_f, const double 
 //   plain CG applies with z = P^-1 (rhs - A x) as residual.  One reduction point per iteration:
 //       [k_schur_p]   x += alpha p; z' = z - alpha q; p' = z' + beta p; v = A p'; gamma = <z',z'>_Z
 //       [3 DCT passes] q' = P^-1 v with <p',q'>_Z and <q',q'>_Z
-//       [k_fin_cg_step] alpha' = gamma / <p',q'>;  gamma' ~ alpha'^2 <q',q'> - gamma  (the value
+//       [start of the next k_schur_p] alpha' = gamma / <p',q'>;  gamma' ~ alpha'^2 <q',q'> - gamma  (the value
 //                     <z'',z''>_Z will take, by conjugacy);  beta' = gamma'/gamma;  stop test on gamma'
 //   gamma itself is always the directly summed <z',z'>_Z of the previous line; the predicted
 //   gamma' only steers beta and the stop test, and a prediction lost in cancellation
@@ -1271,38 +1324,76 @@ __global__ __launch_bounds__(NTH) void k_ramp(Geom G, int tiles_f, const double 
 //       beta = <r',r'>_Z' / <r,r>_Z'; ph = r' + beta ph.
 // =================================================================================
 
-// FIRST: p_new = z, v = A p_new.  Otherwise the pending step is applied on the way:
+// Iteration k of the forward CG (it = k; FIRST: k = 0, p_new = z, v = A p_new).  For k >= 1 every
+// workgroup first resolves the reduction point of iteration k-1 from its partial sums (gpart/gpart2 from
+// the preconditioner epilogue, part[., (k-1)&1] from the previous launch of this kernel) -- the same
+// arithmetic on the same numbers in every workgroup; the workgroup with blk == 0 records the result --
+// and then applies that step on the way:
 //   x += alpha p_old; z_new = z - alpha q; p_new = z_new + beta p_old (z_new and p_new recomputed on
 //   the halo, z_new written to its own buffer so that neighbours still read z), v = A p_new, and the
-//   partial of <z_new, z_new>_Z goes to part[.,0].
+//   partial of <z_new, z_new>_Z goes to part[., k&1].  A trajectory that the step brings below the
+//   tolerance only takes the step (x += alpha p_old).
 template <int FIRST>
-__global__ __launch_bounds__(NTH) void k_schur_p(Geom G, Phys P, const TrajState *__restrict__ st,
+__global__ __launch_bounds__(NTH) void k_schur_p(Geom G, Phys P, TrajState *__restrict__ st,
                                                  long slot_stride, const double *__restrict__ z,
                                                  const double *__restrict__ q, const double *__restrict__ p_old,
                                                  const double *__restrict__ D_s, double dt,
                                                  double *__restrict__ x, double *__restrict__ z_new,
                                                  double *__restrict__ p_new, double *__restrict__ v,
-                                                 double *__restrict__ part) {
+                                                 double *__restrict__ part, const double *__restrict__ gpart,
+                                                 const double *__restrict__ gpart2, int gnblk, int it, double tol,
+                                                 int maxit) {
     TILE_COORDS;
-    const TrajState S = st[b];
-    if (!S.lin_active) return;
     __shared__ double sx[(TY + 4) * (TX + 4)];
     __shared__ double stt[(TY + 2) * (TX + 2)];
     __shared__ double sred[NPART * 4];
     constexpr int W2 = TX + 4, W1 = TX + 2;
     const long pb = b * G.plane;
+    const int rd = (it + 1) & 1, wr = it & 1;          // per-iteration state copies / partial slots
+    const int slot = st[b].slot;
+    const double dbar = st[b].dbar;
+    double alpha = 0.0, beta = 0.0;
     if (FIRST) {
+        if (!st[b].ci_active[0]) return;
         load_tile<2>(sx, z + pb, G, c0, r0);
     } else {
+        const int was_active = st[b].ci_active[rd];
+        if (!was_active) {
+            if (blk == 0 && threadIdx.x == 0) {           // hand the (finished) state on to the other copy
+                st[b].ci_active[wr] = 0;
+                st[b].ci_it[wr] = st[b].ci_it[rd];
+                st[b].ci_gamma[wr] = st[b].ci_gamma[rd];
+            }
+            return;
+        }
+        const double gamma0 = st[b].cg_gamma0, gamma_old = st[b].ci_gamma[rd];
+        const int it_old = st[b].ci_it[rd];
+        cg_sums(gpart, gpart2, gnblk, part, nblk, rd, it >= 2, b, sred);
+        const CgNext n = cg_next(sred[0], sred[1], it >= 2 ? sred[2] : gamma_old, gamma0, it_old, tol, maxit);
+        __syncthreads();                                   // sred is reused below
+        if (blk == 0 && threadIdx.x == 0) cg_record(st[b], n, wr);
+        alpha = n.alpha;
+        beta = n.beta;
+        if (!n.active) {                                   // converged (or broke down, alpha = 0): take the step only
+            if (!n.breakdown)
+                for (int k = 0; k < TY / 4; ++k) {
+                    int r = r0 + ly0 + 4 * k, c = c0 + lx;
+                    if (r < G.ns && c < G.nf) {
+                        long o = pb + (long)r * G.pitch + c;
+                        x[o] += alpha * p_old[o];
+                    }
+                }
+            return;
+        }
         for (int e = threadIdx.x; e < W2 * (TY + 4); e += NTH) {
             int ly = e / W2, lxx = e - ly * W2;
             int gr = refl(r0 - 2 + ly, G.ns), gc = refl(c0 - 2 + lxx, G.nf);
             long o = pb + (long)gr * G.pitch + gc;
-            sx[e] = (z[o] - S.cg_alpha * q[o]) + S.cg_beta * p_old[o];
+            sx[e] = (z[o] - alpha * q[o]) + beta * p_old[o];
         }
     }
     __syncthreads();
-    const double *Dp = D_s + S.slot * slot_stride + pb;
+    const double *Dp = D_s + slot * slot_stride + pb;
     for (int e = threadIdx.x; e < (TY + 2) * W1; e += NTH) {
         int ly = e / W1, lxx = e - ly * W1;
         int gr = refl(r0 - 1 + ly, G.ns), gc = refl(c0 - 1 + lxx, G.nf);
@@ -1319,10 +1410,10 @@ __global__ __launch_bounds__(NTH) void k_schur_p(Geom G, Phys P, const TrajState
             long o = pb + (long)r * G.pitch + c;
             if (!FIRST) {
                 double po = p_old[o];
-                double zn = z[o] - S.cg_alpha * q[o];
-                x[o] += S.cg_alpha * po;
+                double zn = z[o] - alpha * q[o];
+                x[o] += alpha * po;
                 z_new[o] = zn;
-                acc[0] += wdev(r, c, G) * (Dp[(long)r * G.pitch + c] - S.dbar) * (zn * zn);
+                acc[0] += wdev(r, c, G) * (Dp[(long)r * G.pitch + c] - dbar) * (zn * zn);
             }
             p_new[o] = sx[p2];
             v[o] = sx[p2] * idt - lap_at<W1>(stt, p1, G.ax, G.ay);
@@ -1330,7 +1421,7 @@ __global__ __launch_bounds__(NTH) void k_schur_p(Geom G, Phys P, const TrajState
     }
     if (!FIRST) {
         const int op[1] = {0};
-        block_reduce_store<1>(acc, op, sred, part + ((long)b * nblk + blk) * NPART);
+        block_reduce_store<1>(acc, op, sred, part + ((long)b * nblk + blk) * NPART + wr);
     }
 }
 
