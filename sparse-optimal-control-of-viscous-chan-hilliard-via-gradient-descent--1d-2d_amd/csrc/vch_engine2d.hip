@@ -50,6 +50,9 @@ struct vch2d_ctx {
     double *Q1f, *Q2f, *Q1s, *Q2s, *mf, *ms;
     bool use_fft;                         // both axes power-of-two: in-LDS FFT instead of the GEMMs
     FftAxis fax, sax;
+    FftAxis fax_h, sax_h;                 // half-length plans (FFT length N) of the half-size DCT-I, N = 512 only
+    double2 *tw_fh = nullptr, *tw_sh = nullptr;
+    bool half_f = false, half_s = false;
     double2 *tw_f, *tw_s;
     // resident histories [B][Mmax+1][plane] (lazy)
     double *phi_hist, *u_hist, *u_trial, *phi_trial, *phiQ, *r_hist, *p_hist, *q_hist;
@@ -301,7 +304,20 @@ extern "C" vch2d_ctx *vch2d_create(const vch2d_params *p, int batch, int max_ste
                 return true;
             };
             if (!mk(p->Nx, &c->tw_f, c->fax) || !mk(p->Ny, &c->tw_s, c->sax)) return fail("FFT twiddle upload");
-            {
+            // half-size DCT-I (vch_fft.h, k_dcth_*) where the axis has 512 intervals: opt-in (VCH_DCT_HALF=1), it does half
+            // the butterflies but measured 5-30 % slower per pass on MI355X (profiles/r01_c_fft_variants.txt)
+            const bool want_half = getenv("VCH_DCT_HALF") != nullptr;
+            if (want_half && p->Nx == HN) {
+                if (!mk(HN / 2, &c->tw_fh, c->fax_h)) return fail("FFT twiddle upload");
+                c->half_f = true;
+            }
+            if (want_half && p->Ny == HN) {
+                if (!mk(HN / 2, &c->tw_sh, c->sax_h)) return fail("FFT twiddle upload");
+                c->half_s = true;
+            }
+            if (c->half_f) {
+                c->gnblk = (G.ns + 3) / 4;
+            } else {
                 const int Cc = c->fax.L <= 1024 ? 1024 : c->fax.L;
                 const int rpw = 2 * (Cc >> c->fax.logL);
                 c->gnblk = (G.ns + rpw - 1) / rpw;
@@ -325,6 +341,8 @@ extern "C" void vch2d_destroy(vch2d_ctx *c) {
         if (q) hipFree(q);
     hipFree(c->st);
     hipFree(c->frozen_dev);
+    if (c->tw_fh) hipFree(c->tw_fh);
+    if (c->tw_sh) hipFree(c->tw_sh);
     if (c->tw_f) hipFree(c->tw_f);
     if (c->tw_s) hipFree(c->tw_s);
     hipHostFree(c->st_host);
@@ -384,13 +402,23 @@ static int precond(vch2d_ctx *c, const double *in, long in_slot_stride, double *
         else if (c->fax.logL == 11) DCT_ROWS(EPI_, 2048, 11, in_, iss_, out_);    \
         else DCT_ROWS(EPI_, 4096, 0, in_, iss_, out_);                            \
     } while (0)
-        DCT_ROWS_ANY(0, in, in_slot_stride, c->t1);
-        if (c->sax.logL == 10) DCT_COLS(1024, 10);
+#define DCTH_ROWS(EPI_, in_, iss_, out_)                                                                        \
+    LAUNCHC(PC_GEMM, (k_dcth_rows<EPI_>), dim3((ns + 3) / 4, 1, c->B), dim3(HT), G, c->fax, c->fax_h, in_, iss_, out_, 1.0, sp, \
+            c->st, gate)
+        if (c->half_f) DCTH_ROWS(0, in, in_slot_stride, c->t1);
+        else DCT_ROWS_ANY(0, in, in_slot_stride, c->t1);
+        if (c->half_s)
+            LAUNCHC(PC_GEMM, k_dcth_cols, dim3((nf + 3) / 4, 1, c->B), dim3(HT), G, c->sax, c->sax_h, (const double *)c->t1, c->t2,
+                    scale, sp, c->st, gate);
+        else if (c->sax.logL == 10) DCT_COLS(1024, 10);
         else if (c->sax.logL == 9) DCT_COLS(1024, 9);
         else if (c->sax.logL < 10) DCT_COLS(1024, 0);
         else if (c->sax.logL == 11) DCT_COLS(2048, 11);
         else DCT_COLS(4096, 0);
-        if (last == 3) DCT_ROWS_ANY(3, (const double *)c->t2, 0L, out);
+        if (c->half_f) {
+            if (last == 3) DCTH_ROWS(3, (const double *)c->t2, 0L, out);
+            else DCTH_ROWS(0, (const double *)c->t2, 0L, out);
+        } else if (last == 3) DCT_ROWS_ANY(3, (const double *)c->t2, 0L, out);
         else DCT_ROWS_ANY(0, (const double *)c->t2, 0L, out);
         return 0;
     }

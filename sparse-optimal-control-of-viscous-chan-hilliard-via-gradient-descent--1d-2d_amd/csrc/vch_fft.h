@@ -289,3 +289,256 @@ __global__ __launch_bounds__(FftThreads<C>::T) void k_dct_cols(Geom G, FftAxis a
         if (col < G.nf) ob[(long)r * G.pitch + col] = sb[2 * PADC((cc >> 1) * L + r) + (cc & 1)];
     }
 }
+
+// =====================================================================================================
+// Half-size DCT-I for N = 512 intervals (the 512^2 grid), OPT-IN with VCH_DCT_HALF=1 (parity-tested, but not faster on
+// MI355X at the batch sizes of the bench: the passes are latency-bound there, see profiles/r01_c_fft_variants.txt).
+// E of a real sequence x_0..x_N needs only a
+// real FFT of length N (instead of the complex FFT of its even extension, length 2N, shared by two rows):
+//     y_n = (x_n + x_{N-n})/2 - sin(pi n/N) (x_n - x_{N-n}),  n = 0..N-1;     Y = FFT_N(y)
+//     E_{2k}   = 2 Re Y_k,                                      k = 0..N/2
+//     E_{2k+1} = 2 (X_1 - sum_{j=1..k} Im Y_j),                 X_1 = (x_0 - x_N)/2 + sum_{0<n<N} x_n cos(pi n/N)
+// Two rows a, b share ONE complex FFT of length N (z = y_a + i y_b, untangled afterwards), so a workgroup
+// image of 1024 complex doubles now carries FOUR rows: half the butterflies and LDS passes per row.  Each
+// wavefront owns one transform in the pre- and post-passes (64 lanes x 8 points), so the running sum of the
+// odd outputs is a wavefront scan and X_1 a wavefront sum.  Accuracy against the long transform: 2e-15 of the
+// largest coefficient (tests/test_gpu_2d.py::test_spectral_solve...; the true residual of a converged solve
+// moves from 5e-16 to 6e-15), irrelevant for a preconditioner.
+// =====================================================================================================
+constexpr int HN = 512, HLOGN = 9, HC = 1024, HT = 128;
+
+__device__ __forceinline__ double wave_bcast_sum(double v) { return __shfl(wave_sum(v), 0, 64); }
+__device__ __forceinline__ double wave_excl_scan(double v) {
+    const int lane = threadIdx.x & 63;
+    double inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    return inc - v;
+}
+
+// pre-pass of one transform from registers: xa/xb[j] = x_n, ma/mb[j] = x_{N-n} for n = l + 64 j; writes the
+// packed sequence into image f and returns the two X_1 sums
+__device__ __forceinline__ void dcth_pre(double2 *buf, const FftAxis &axL, int f, int l, const double (&xa)[8],
+                                         const double (&ma)[8], const double (&xb)[8], const double (&mb)[8],
+                                         double &x1a, double &x1b) {
+    double sa = 0.0, sb = 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int n = l + 64 * j;
+        const double2 t = axL.tw[n];                     // exp(-i pi n / N): cos = t.x, sin = -t.y
+        const double ya = 0.5 * (xa[j] + ma[j]) + t.y * (xa[j] - ma[j]);
+        const double yb = 0.5 * (xb[j] + mb[j]) + t.y * (xb[j] - mb[j]);
+        buf[PADC(f * HN + n)] = make_double2(ya, yb);
+        if (n == 0) {
+            sa += 0.5 * (xa[j] - ma[j]);
+            sb += 0.5 * (xb[j] - mb[j]);
+        } else {
+            sa += t.x * xa[j];
+            sb += t.x * xb[j];
+        }
+    }
+    x1a = wave_bcast_sum(sa);
+    x1b = wave_bcast_sum(sb);
+}
+
+// post-pass of one transform: lane l gets E_{8l .. 8l+7} of both rows (ea, eb) and lane 63 also E_N (eNa, eNb)
+__device__ __forceinline__ void dcth_post(const double2 *buf, int f, int l, double x1a, double x1b, double (&ea)[8],
+                                          double (&eb)[8], double &eNa, double &eNb) {
+    double da[4], db[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = 4 * l + j;
+        const double2 zk = buf[PADC(f * HN + k)], zm = buf[PADC(f * HN + ((HN - k) & (HN - 1)))];
+        ea[2 * j] = 0.5 * (zk.x + zm.x);                 // Re Y_a
+        eb[2 * j] = 0.5 * (zk.y + zm.y);                 // Re Y_b
+        da[j] = k == 0 ? 0.0 : -0.5 * (zk.y - zm.y);     // -Im Y_a
+        db[j] = k == 0 ? 0.0 : 0.5 * (zk.x - zm.x);      // -Im Y_b
+    }
+#pragma unroll
+    for (int j = 1; j < 4; ++j) {
+        da[j] += da[j - 1];
+        db[j] += db[j - 1];
+    }
+    const double oa = x1a + wave_excl_scan(da[3]), ob = x1b + wave_excl_scan(db[3]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        ea[2 * j + 1] = oa + da[j];
+        eb[2 * j + 1] = ob + db[j];
+    }
+    const double2 zh = buf[PADC(f * HN + HN / 2)];
+    eNa = zh.x;
+    eNb = zh.y;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        ea[j] *= 2.0;
+        eb[j] *= 2.0;
+    }
+    eNa *= 2.0;
+    eNb *= 2.0;
+}
+
+// E along the fast axis, 4 rows per workgroup.  EPI as in k_dct_rows.
+template <int EPI>
+__global__ __launch_bounds__(HT) void k_dcth_rows(Geom G, FftAxis axL, FftAxis axN, const double *__restrict__ in,
+                                                  long in_slot_stride, double *__restrict__ out, double scale, SpecArgs sp,
+                                                  const TrajState *__restrict__ st, int gate) {
+    const int b = blockIdx.z;
+    if (gate && !gate_open(st[b], gate)) return;
+    __shared__ double2 buf[HC];
+    const int tid = threadIdx.x, f = tid >> 6, l = tid & 63;
+    const int ra = blockIdx.x * 4 + 2 * f, rb = ra + 1;
+    const bool va = ra < G.ns, vb = rb < G.ns;
+    const double *ib = in + b * G.plane + (in_slot_stride ? st[b].slot * in_slot_stride : 0);
+    const double *pa = ib + (long)ra * G.pitch, *pb = ib + (long)rb * G.pitch;
+    double xa[8], ma[8], xb[8], mb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int n = l + 64 * j;
+        xa[j] = va ? pa[n] : 0.0;
+        ma[j] = va ? pa[HN - n] : 0.0;
+        xb[j] = vb ? pb[n] : 0.0;
+        mb[j] = vb ? pb[HN - n] : 0.0;
+    }
+    double x1a, x1b;
+    dcth_pre(buf, axL, f, l, xa, ma, xb, mb, x1a, x1b);
+    __syncthreads();
+    fft_lds<HC, HLOGN>(buf, axN);
+    double ea[8], eb[8], eNa, eNb;
+    dcth_post(buf, f, l, x1a, x1b, ea, eb, eNa, eNb);
+    double dot = 0.0, dot2 = 0.0, dbar = 0.0;
+    const double *Dp = nullptr, *Ob = nullptr;
+    if (EPI == 3) {
+        dbar = st[b].dbar;
+        Dp = sp.Dslot + st[b].slot * sp.d_slot_stride + b * G.plane;
+        Ob = sp.other ? sp.other + b * G.plane : nullptr;
+    }
+    double *ob = out + b * G.plane;
+    auto put = [&](int row, int k, double e) {
+        const double v = scale * e;
+        const long o = (long)row * G.pitch + k;
+        ob[o] = v;
+        if (EPI == 3) {
+            const double wd = wdev(row, k, G) * (Dp[o] - dbar);
+            dot += wd * ((Ob ? Ob[o] : v) * v);
+            dot2 += wd * (v * v);
+        }
+    };
+    // lane l holds outputs 8l..8l+7: turned through the (wave-private) image so that consecutive lanes
+    // store consecutive elements (and the epilogue reads D / other coalesced)
+    double *ra_ = reinterpret_cast<double *>(buf) + (long)f * 2 * HN, *rb_ = ra_ + HN;
+    __syncthreads();                               // all post-pass reads of the image are done
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        ra_[8 * l + j] = ea[j];
+        rb_[8 * l + j] = eb[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = l + 64 * j;
+        if (va) put(ra, k, ra_[k]);
+        if (vb) put(rb, k, rb_[k]);
+    }
+    if (l == 63) {
+        if (va) put(ra, HN, eNa);
+        if (vb) put(rb, HN, eNb);
+    }
+    if (EPI == 3) {
+        dot = wave_sum(dot);
+        dot2 = wave_sum(dot2);
+        __syncthreads();
+        double *sred = reinterpret_cast<double *>(buf);
+        if (l == 0) {
+            sred[f] = dot;
+            sred[2 + f] = dot2;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            sp.gpart[(long)b * gridDim.x + blockIdx.x] = sred[0] + sred[1];
+            sp.gpart2[(long)b * gridDim.x + blockIdx.x] = sred[2] + sred[3];
+        }
+    }
+}
+
+// E along the slow axis for 4 columns, spectral multiplier, E again (one load, one store).
+__global__ __launch_bounds__(HT) void k_dcth_cols(Geom G, FftAxis axL, FftAxis axN, const double *__restrict__ in,
+                                                  double *__restrict__ out, double scale, SpecArgs sp,
+                                                  const TrajState *__restrict__ st, int gate) {
+    const int b = blockIdx.z;
+    if (gate && !gate_open(st[b], gate)) return;
+    __shared__ double2 buf[HC];
+    const int tid = threadIdx.x, f = tid >> 6, l = tid & 63;
+    const int ca = xcd_remap(blockIdx.x, gridDim.x) * 4 + 2 * f, cb = ca + 1;
+    const bool va = ca < G.nf, vb = cb < G.nf;
+    const double *ib = in + b * G.plane;
+    double xa[8], ma[8], xb[8], mb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int n = l + 64 * j;
+        const double *pn = ib + (long)n * G.pitch, *pm = ib + (long)(HN - n) * G.pitch;
+        xa[j] = va ? pn[ca] : 0.0;
+        ma[j] = va ? pm[ca] : 0.0;
+        xb[j] = vb ? pn[cb] : 0.0;
+        mb[j] = vb ? pm[cb] : 0.0;
+    }
+    double x1a, x1b;
+    dcth_pre(buf, axL, f, l, xa, ma, xb, mb, x1a, x1b);
+    __syncthreads();
+    fft_lds<HC, HLOGN>(buf, axN);
+    double ea[8], eb[8], eNa, eNb;
+    dcth_post(buf, f, l, x1a, x1b, ea, eb, eNa, eNb);
+    // spectral multiplier on E (mode kk along the slow axis, column along the fast axis)
+    const double c1 = sp.c1a + sp.c1b * st[b].dbar;
+    const double mfa = sp.mf[va ? ca : G.nf - 1], mfb = sp.mf[vb ? cb : G.nf - 1];
+    auto mul = [&](int kk, double mfc, double e) {
+        const double m = sp.ms[kk] + mfc;
+        return e * (scale / (sp.c0 + m * (c1 + sp.c2 * m)));
+    };
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        ea[j] = mul(8 * l + j, mfa, ea[j]);
+        eb[j] = mul(8 * l + j, mfb, eb[j]);
+    }
+    eNa = mul(HN, mfa, eNa);
+    eNb = mul(HN, mfb, eNb);
+    // the scaled spectrum becomes the input of the second transform: through the (wave-private) image as two
+    // real arrays of N entries each; entry N travels by shuffle from lane 63
+    double *ra_ = reinterpret_cast<double *>(buf) + (long)f * 2 * HN, *rb_ = ra_ + HN;
+    __syncthreads();                               // all post-pass reads of the image are done
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        ra_[8 * l + j] = ea[j];
+        rb_[8 * l + j] = eb[j];
+    }
+    const double xNa = __shfl(eNa, 63, 64), xNb = __shfl(eNb, 63, 64);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int n = l + 64 * j;
+        xa[j] = ra_[n];
+        xb[j] = rb_[n];
+        ma[j] = n == 0 ? xNa : ra_[HN - n];
+        mb[j] = n == 0 ? xNb : rb_[HN - n];
+    }
+    __syncthreads();                               // reads done before the image is overwritten
+    dcth_pre(buf, axL, f, l, xa, ma, xb, mb, x1a, x1b);
+    __syncthreads();
+    fft_lds<HC, HLOGN>(buf, axN);
+    dcth_post(buf, f, l, x1a, x1b, ea, eb, eNa, eNb);
+    double *ob = out + b * G.plane;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        double *po = ob + (long)(8 * l + j) * G.pitch;
+        if (va) po[ca] = ea[j];
+        if (vb) po[cb] = eb[j];
+    }
+    if (l == 63) {
+        double *po = ob + (long)HN * G.pitch;
+        if (va) po[ca] = eNa;
+        if (vb) po[cb] = eNb;
+    }
+}
+

@@ -46,6 +46,7 @@ def _eng(V, g=None, B=1, max_steps=16, **kw):
 # ---------------------------------------------------------------------------------------
 @pytest.mark.parametrize("shape", [(16, 16, 1.0, 1.0), (12, 9, 1.0, 0.7), (70, 45, 1.3, 0.9), (129, 64, 1.0, 1.0),
                                    (128, 128, 1.0, 1.0), (64, 32, 1.0, 0.5), (32, 256, 2.0, 1.0), (1024, 1024, 1.0, 1.0),
+                                   (512, 512, 1.0, 1.0), (512, 32, 1.0, 0.3), (64, 512, 1.0, 2.0),
                                    (2048, 16, 1.0, 1.0), (16, 2048, 1.0, 1.0)])
 def test_spectral_solve_matches_operator(V, O2, shape):
     """Both DCT back ends (MFMA f64 GEMM for general grids, in-LDS FFT of every image size for
@@ -194,6 +195,32 @@ def test_linear_solve_degenerate_right_hand_sides(V, O2):
         n = (N + 1) ** 2
         assert relerr(dphi[k].ravel(), ref[:n]) < SOLVE and relerr(dmu[k].ravel(), ref[n:]) < SOLVE, (k, st)
     assert st["max_lin_relres"] <= 1e-14
+
+
+def test_half_size_dct_variant(V, O2, monkeypatch):
+    """The opt-in half-size DCT-I (VCH_DCT_HALF=1: real-even algorithm on an FFT of length N, 512-interval axes
+    only): the spectral solve inverts the operator, and a Newton step agrees with the long transform."""
+    monkeypatch.setenv("VCH_DCT_HALF", "1")
+    rng = np.random.default_rng(9)
+    for Nx, Ny in ((512, 512), (512, 16), (32, 512)):
+        e = V.Engine2D(Nx=Nx, Ny=Ny, batch=2)
+        v = rng.standard_normal((2, Nx + 1, Ny + 1))
+        z = e.spectral_solve(7.0, 0.9, 3e-3, v)
+        hx, hy = 1.0 / Nx, 1.0 / Ny
+        Mz = np.stack([-O2.lap(a, hx, hy) for a in z])
+        back = 7.0 * z + 0.9 * Mz + 3e-3 * np.stack([-O2.lap(a, hx, hy) for a in Mz])
+        assert relerr(back, v) < 1e-6       # the check multiplies by the operator (cond ~ 1e9): round-off amplified
+        e.close()
+    N = 512
+    phi = O2.init_phi_random(N, N, 1e-2, amp=0.1, seed=42)
+    w = np.zeros_like(phi)
+    eh = V.Engine2D(Nx=N, Ny=N, max_steps=2)
+    ph, mh, hh, _ = eh.newton_raphson(phi, eh.initialize_mu(phi, w), w, w, 1e-3)
+    eh.close()
+    monkeypatch.delenv("VCH_DCT_HALF")
+    ef = V.Engine2D(Nx=N, Ny=N, max_steps=2)
+    pf, mf, hf, _ = ef.newton_raphson(phi, ef.initialize_mu(phi, w), w, w, 1e-3)
+    assert len(hh) == len(hf) and np.allclose(hh[:-1], hf[:-1], rtol=1e-6) and relerr(ph, pf) < 1e-11
 
 
 # ---------------------------------------------------------------------------------------
