@@ -646,8 +646,7 @@ extern "C" int vch2d_schur_apply(vch2d_ctx *c, const double *phi_new, double dt,
     // D into slot 0 through the solve set-up kernel (a = b = x, results other than D unused)
     LAUNCH(k_solve_setup, c->grid, dim3(NTH), c->G, c->P, c->tmp[1], c->tmp[1], c->tmp[0], dt, c->Rphi_s, c->rhs_s, c->D_s,
            c->part);
-    LAUNCH((k_schur<0>), c->grid, dim3(NTH), c->G, c->P, (const TrajState *)nullptr, c->slot_stride, c->tmp[1], c->D_s,
-           c->rhs_s, dt, c->tmp[2], c->part);
+    LAUNCH(k_schur, c->grid, dim3(NTH), c->G, c->P, (const TrajState *)nullptr, c->slot_stride, c->tmp[1], c->D_s, dt, c->tmp[2]);
     return d2h(c, out, c->tmp[2], c->B);
 }
 

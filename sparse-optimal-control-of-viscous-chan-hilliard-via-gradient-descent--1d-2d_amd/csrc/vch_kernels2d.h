@@ -30,7 +30,7 @@ struct TrajState {
     double alpha;        // step of the pending trial
     double best_norm, best_alpha;
     double Dmin, Dmax, dbar;   // range of the Jacobian diagonal, preconditioner shift
-    double rho, theta;         // contraction bound of the Richardson sweep, stagnation threshold
+    double rho;                // bound of the CG contraction per iteration from the spectrum of P^-1 A (cg_setup)
     long newton_total;         // residual norms recorded over the whole march
     // linear solve (preconditioned CG on the Schur system)
     int lin_active, lin_it;
@@ -337,29 +337,16 @@ __global__ __launch_bounds__(NTH) void k_residual(Geom G, Phys P, const TrajStat
 }
 
 // ---------------------------------------------------------------------------------
-// Schur-reduced Newton operator  A x = x/dt + M (kappa/2 M x + D x),  M = -L   (13-point).
-//   MODE 0: out = A x                      (vch2d_schur_apply)
-//   MODE 1: out = rhs[slot] - A x, + sum(out^2) per workgroup   (Richardson residual)
-// This is the "Newton stencil SpMV" of the north star: algorithmic traffic per node is
-// x, D, rhs in and r out = 32 B (24 B in MODE 0).
+// Schur-reduced Newton operator  out = A x = x/dt + M (kappa/2 M x + D x),  M = -L   (13-point), the bare
+// operator of vch2d_schur_apply (kernel-level tests); the solver's own application is fused into k_schur_p.
 // ---------------------------------------------------------------------------------
-template <int MODE>
 __global__ __launch_bounds__(NTH) void k_schur(Geom G, Phys P, const TrajState *__restrict__ st,
                                                long slot_stride, const double *__restrict__ x,
-                                               const double *__restrict__ D_s, const double *__restrict__ rhs_s,
-                                               double dt, double *__restrict__ out, double *__restrict__ part) {
+                                               const double *__restrict__ D_s, double dt, double *__restrict__ out) {
     TILE_COORDS;
-    int slot = 0;
-    if (MODE == 1) {
-        const TrajState S = st[b];
-        if (!S.lin_active) return;
-        slot = S.slot;
-    } else if (st) {
-        slot = st[b].slot;
-    }
+    const int slot = st ? st[b].slot : 0;
     __shared__ double sx[(TY + 4) * (TX + 4)];
     __shared__ double stt[(TY + 2) * (TX + 2)];
-    __shared__ double sred[NPART * 4];
     constexpr int W2 = TX + 4, W1 = TX + 2;
     const long pb = b * G.plane;
     load_tile<2>(sx, x + pb, G, c0, r0);
@@ -372,26 +359,13 @@ __global__ __launch_bounds__(NTH) void k_schur(Geom G, Phys P, const TrajState *
         stt[e] = -0.5 * P.kappa * lap_at<W2>(sx, p2, G.ax, G.ay) + Dp[(long)gr * G.pitch + gc] * sx[p2];
     }
     __syncthreads();
-    double acc[1] = {0.0};
     const double idt = 1.0 / dt;
     for (int k = 0; k < TY / 4; ++k) {
         int ly = ly0 + 4 * k, r = r0 + ly, c = c0 + lx;
         if (r < G.ns && c < G.nf) {
             int p1 = (ly + 1) * W1 + lx + 1, p2 = (ly + 2) * W2 + lx + 2;
-            long o = pb + (long)r * G.pitch + c;
-            double ax_ = sx[p2] * idt - lap_at<W1>(stt, p1, G.ax, G.ay);
-            if (MODE == 0) {
-                out[o] = ax_;
-            } else {
-                double rr = rhs_s[slot * slot_stride + o] - ax_;
-                out[o] = rr;
-                acc[0] += rr * rr;
-            }
+            out[pb + (long)r * G.pitch + c] = sx[p2] * idt - lap_at<W1>(stt, p1, G.ax, G.ay);
         }
-    }
-    if (MODE == 1) {
-        const int op[1] = {0};
-        block_reduce_store<1>(acc, op, sred, part + ((long)b * nblk + blk) * NPART);
     }
 }
 
@@ -895,7 +869,6 @@ __device__ __forceinline__ void cg_setup(TrajState &S, double g0, double cscale,
     S.rho = rate;
     double k = rate > 1e-300 ? log(2.0 / tol) / -log(rate) : 1.0;
     S.lin_budget = (int)fmin(4000.0, ceil(k) + 2.0);
-    S.theta = 0.0;
 }
 
 template <int MODE>
