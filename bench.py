@@ -41,7 +41,7 @@ FP64_MFMA_PEAK_TF = 78.6     # = 1/2 of the 157.3 TF FP32 vector/matrix peak of 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=5)       # K = 5 timed iterations from u0 = 0
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--grid", type=int, default=512, help="Nx = Ny")
     ap.add_argument("--time-steps", type=int, default=1000)
