@@ -197,3 +197,16 @@ def test_pgd_resident_batch_matches_function_seam(V):
     assert list(rs["trials"]) == list(rb["trials"][0])
     assert np.allclose(rs["costs"], rb["costs"][0], rtol=1e-12)
     assert relerr(rs["u"], rb["u"][0]) < 1e-10
+
+
+def test_bitwise_reproducibility_1d(V):
+    F1 = V.module("Vch_control_1D.Forward_solver")
+    N, M = 200, 12
+    _, dts = V.time_grid(M * 1e-2, 1e-2)
+    phi0 = np.stack([F1.init_phi_random(N, 1e-2, amp=0.05, seed=s) for s in (1, 2)])
+    runs = []
+    for rep in range(2):
+        e = V.Engine1D(N=N, batch=2, max_steps=len(dts))
+        runs.append(e.forward(phi0, dts)[0])
+        e.close()
+    assert np.array_equal(runs[0], runs[1])

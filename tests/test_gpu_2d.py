@@ -525,3 +525,23 @@ def test_full_size_pgd_iteration_invariants_512x1000(V, O2):
     assert np.abs(mass - mass[0]).max() <= 1e-10 * np.sum(wts)
     assert np.abs(ph).max() <= 0.99 + 1e-15
 
+
+
+def test_bitwise_reproducibility(V, O2):
+    """All reductions run in a fixed order (per-workgroup partials summed by index, no atomics): two runs of the
+    same march / PGD iteration give bit-identical histories, controls and costs, also from different contexts."""
+    N, T, dt = 64, 0.05, 1e-2
+    t, dts = V.time_grid(T, dt)
+    xs = np.linspace(0, 1, N + 1)
+    phi_T = 0.7 * np.sin(2 * np.pi * xs)[:, None] * np.cos(np.pi * xs)[None, :]
+    phi0 = np.stack([O2.init_phi_random(N, N, 1e-2, amp=0.1, seed=42 + i) for i in range(3)])
+    outs = []
+    for rep in range(2):
+        e = V.Engine2D(Nx=N, Ny=N, batch=3, max_steps=len(dts))
+        ph, _ = e.forward(phi0, dts)
+        J0 = e.pgd_init(phi0, np.stack([phi_T] * 3), t, V.make_opt(), ramp=True, T=T)
+        r = e.pgd_iterate(2)
+        outs.append((ph, J0, r["cost"], e.pgd_get("u"), e.pgd_get("r")))
+        e.close()
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
