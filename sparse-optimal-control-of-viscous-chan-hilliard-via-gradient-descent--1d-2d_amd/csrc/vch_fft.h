@@ -65,6 +65,18 @@ __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
 #else
 #define PADC(c) (c)
 #endif
+// Length 1024 (the 512^2 grid) runs the plan 8 x 8 x 4 x 4 (FFT_R8, four LDS exchanges instead of five); its first
+// two passes write index 8j + r and 64 (j >> 3) + (j & 7) + 8r, for which the slot is XOR-ed with (i3, i4, i5).
+#ifndef FFT_R8
+#define FFT_R8 1
+#endif
+template <int LOGL>
+__device__ __forceinline__ int swz(int c) {
+#if FFT_R8 && FFT_SWZ && !FFT_PAD
+    if (LOGL == 10) return c ^ ((c >> 3) & 7);
+#endif
+    return PADC(c);
+}
 template <int C>
 struct FftLds {
     static constexpr int SIZE = FFT_PAD ? C + C / 4 + 4 : C;
@@ -90,6 +102,58 @@ __device__ __forceinline__ void fft_lds(double2 *buf, const FftAxis ax) {
     const int tid = threadIdx.x;
     const int logL = LOGL ? LOGL : ax.logL, L = 1 << logL;
     int logNs = 0;
+#if FFT_R8
+    if (LOGL == 10) {
+        // two radix-8 passes (Ns = 1, 8): C/8 butterflies = one per thread (C = 1024, T = 128)
+        static_assert(LOGL != 10 || C == 8 * T, "radix-8 plan: one butterfly per thread");
+        constexpr double RH = 0.70710678118654752440;
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const int Ns = ps ? 8 : 1, j = tid, k = j & (Ns - 1);
+            double2 a[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) a[r] = buf[swz<LOGL>(j + r * (L >> 3))];
+            if (ps) {                                   // inputs r = 1..7 times w^r, w = exp(-2 pi i k / 64)
+                const double2 w1 = ax.tw[k << 4];
+                double2 w = w1;
+                a[1] = cmul(a[1], w);
+#pragma unroll
+                for (int r = 2; r < 8; ++r) {
+                    w = cmul(w, w1);
+                    a[r] = cmul(a[r], w);
+                }
+            }
+            // 8-point DFT: b_n = a_n + a_{n+4}; c_n = (a_n - a_{n+4}) W8^n; then two 4-point DFTs (even / odd outputs)
+            double2 bb[4], cc[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                bb[n] = make_double2(a[n].x + a[n + 4].x, a[n].y + a[n + 4].y);
+                cc[n] = make_double2(a[n].x - a[n + 4].x, a[n].y - a[n + 4].y);
+            }
+            cc[1] = make_double2(RH * (cc[1].x + cc[1].y), RH * (cc[1].y - cc[1].x));      // * (1 - i)/sqrt 2
+            cc[2] = make_double2(cc[2].y, -cc[2].x);                                       // * (-i)
+            cc[3] = make_double2(RH * (cc[3].y - cc[3].x), -RH * (cc[3].x + cc[3].y));     // * (-1 - i)/sqrt 2
+            double2 o[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const double2 *v = h ? cc : bb;
+                const double2 t0 = make_double2(v[0].x + v[2].x, v[0].y + v[2].y), t1 = make_double2(v[0].x - v[2].x, v[0].y - v[2].y);
+                const double2 t2 = make_double2(v[1].x + v[3].x, v[1].y + v[3].y);
+                const double2 t3 = make_double2(v[1].y - v[3].y, -(v[1].x - v[3].x));      // -i (v1 - v3)
+                o[h + 0] = make_double2(t0.x + t2.x, t0.y + t2.y);
+                o[h + 2] = make_double2(t1.x + t3.x, t1.y + t3.y);
+                o[h + 4] = make_double2(t0.x - t2.x, t0.y - t2.y);
+                o[h + 6] = make_double2(t1.x - t3.x, t1.y - t3.y);
+            }
+            const int wb = ((j >> (3 * ps)) << (3 * ps + 3)) + k;
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 8; ++r) buf[swz<LOGL>(wb + r * Ns)] = o[r];
+            __syncthreads();
+        }
+        logNs = 6;
+    }
+#endif
     // radix-4 passes: C/4 butterflies = 4 per thread
     const int logQ = logL - 2, Q = L >> 2;
 #pragma unroll
@@ -112,8 +176,8 @@ __device__ __forceinline__ void fft_lds(double2 *buf, const FftAxis ax) {
             const int idx = tid + i * T;
             const int f = idx >> logQ, j = idx & (Q - 1), k = j & (Ns - 1);
             const int fb = f * L;
-            double2 a = buf[PADC(fb + j)], b = buf[PADC(fb + j + Q)], c = buf[PADC(fb + j + 2 * Q)],
-                    d = buf[PADC(fb + j + 3 * Q)];
+            double2 a = buf[swz<LOGL>(fb + j)], b = buf[swz<LOGL>(fb + j + Q)], c = buf[swz<LOGL>(fb + j + 2 * Q)],
+                    d = buf[swz<LOGL>(fb + j + 3 * Q)];
             if (logNs > 0) {
                 if (!shared_tw) {
                     const int ti = k << (logL - logNs - 2);
@@ -138,7 +202,7 @@ __device__ __forceinline__ void fft_lds(double2 *buf, const FftAxis ax) {
 #pragma unroll
         for (int i = 0; i < NB4; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) buf[PADC(wbase[i] + r * Ns)] = v[i][r];
+            for (int r = 0; r < 4; ++r) buf[swz<LOGL>(wbase[i] + r * Ns)] = v[i][r];
         __syncthreads();
     }
     if (logNs < logL) {          // one radix-2 pass: C/2 butterflies = 8 per thread
@@ -150,7 +214,7 @@ __device__ __forceinline__ void fft_lds(double2 *buf, const FftAxis ax) {
             const int idx = tid + i * T;
             const int f = idx >> logH, j = idx & (H - 1), k = j & (Ns - 1);
             const int fb = f * L;
-            double2 a = buf[PADC(fb + j)], b = cmul(buf[PADC(fb + j + H)], ax.tw[k << (logL - logNs - 1)]);
+            double2 a = buf[swz<LOGL>(fb + j)], b = cmul(buf[swz<LOGL>(fb + j + H)], ax.tw[k << (logL - logNs - 1)]);
             v[i][0] = make_double2(a.x + b.x, a.y + b.y);
             v[i][1] = make_double2(a.x - b.x, a.y - b.y);
             wbase[i] = f * L + ((j >> logNs) << (logNs + 1)) + k;
@@ -158,8 +222,8 @@ __device__ __forceinline__ void fft_lds(double2 *buf, const FftAxis ax) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < NB2; ++i) {
-            buf[PADC(wbase[i])] = v[i][0];
-            buf[PADC(wbase[i] + Ns)] = v[i][1];
+            buf[swz<LOGL>(wbase[i])] = v[i][0];
+            buf[swz<LOGL>(wbase[i] + Ns)] = v[i][1];
         }
         __syncthreads();
     }
@@ -188,8 +252,8 @@ __global__ __launch_bounds__(FftThreads<C>::T) void k_dct_rows(Geom G, FftAxis a
         const int ra = row0 + 2 * f, rb = ra + 1;
         double2 v = make_double2(ra < G.ns ? ib[(long)ra * G.pitch + j] : 0.0,
                                  rb < G.ns ? ib[(long)rb * G.pitch + j] : 0.0);
-        buf[PADC(f * L + j)] = v;
-        if (j > 0 && j < N) buf[PADC(f * L + L - j)] = v;
+        buf[swz<LOGL>(f * L + j)] = v;
+        if (j > 0 && j < N) buf[swz<LOGL>(f * L + L - j)] = v;
     }
     __syncthreads();
     FFT_STAMP(1);
@@ -207,7 +271,7 @@ __global__ __launch_bounds__(FftThreads<C>::T) void k_dct_rows(Geom G, FftAxis a
         const int rr = nfft == 1 ? (idx >= n1 ? 1 : 0) : (int)(((float)idx + 0.5f) * inv_n1), k = idx - rr * n1;
         const int row = row0 + rr;
         if (row < G.ns) {
-            const double2 c = buf[PADC((rr >> 1) * L + k)];
+            const double2 c = buf[swz<LOGL>((rr >> 1) * L + k)];
             const double v = scale * ((rr & 1) ? c.y : c.x);
             const long o = (long)row * G.pitch + k;
             ob[o] = v;
@@ -263,8 +327,8 @@ __global__ __launch_bounds__(FftThreads<C>::T) void k_dct_cols(Geom G, FftAxis a
         const int col = col0 + cc;
         const double v = col < G.nf ? ib[(long)r * G.pitch + col] : 0.0;
         const int f = cc >> 1, comp = cc & 1;
-        sb[2 * PADC(f * L + r) + comp] = v;
-        if (r > 0 && r < N) sb[2 * PADC(f * L + L - r) + comp] = v;
+        sb[2 * swz<LOGL>(f * L + r) + comp] = v;
+        if (r > 0 && r < N) sb[2 * swz<LOGL>(f * L + L - r) + comp] = v;
     }
     __syncthreads();
     fft_lds<C, LOGL>(buf, ax);
@@ -274,11 +338,11 @@ __global__ __launch_bounds__(FftThreads<C>::T) void k_dct_cols(Geom G, FftAxis a
         const int ks = k <= N ? k : L - k;
         const int ca = col0 + 2 * f, cb = ca + 1;
         const double msk = sp.ms[ks];
-        double2 v = buf[PADC(idx)];
+        double2 v = buf[swz<LOGL>(idx)];
         double ma = msk + sp.mf[ca < G.nf ? ca : G.nf - 1], mb = msk + sp.mf[cb < G.nf ? cb : G.nf - 1];
         v.x *= scale / (sp.c0 + ma * (c1 + sp.c2 * ma));
         v.y *= scale / (sp.c0 + mb * (c1 + sp.c2 * mb));
-        buf[PADC(idx)] = v;
+        buf[swz<LOGL>(idx)] = v;
     }
     __syncthreads();
     fft_lds<C, LOGL>(buf, ax);
@@ -286,7 +350,7 @@ __global__ __launch_bounds__(FftThreads<C>::T) void k_dct_cols(Geom G, FftAxis a
     for (int idx = tid; idx < n1 * ncol; idx += T) {
         const int r = idx >> lc, cc = idx & (ncol - 1);
         const int col = col0 + cc;
-        if (col < G.nf) ob[(long)r * G.pitch + col] = sb[2 * PADC((cc >> 1) * L + r) + (cc & 1)];
+        if (col < G.nf) ob[(long)r * G.pitch + col] = sb[2 * swz<LOGL>((cc >> 1) * L + r) + (cc & 1)];
     }
 }
 
