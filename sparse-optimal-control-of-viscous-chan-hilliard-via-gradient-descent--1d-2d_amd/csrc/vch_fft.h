@@ -65,15 +65,16 @@ __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
 #else
 #define PADC(c) (c)
 #endif
-// Length 1024 (the 512^2 grid) runs the plan 8 x 8 x 4 x 4 (FFT_R8, four LDS exchanges instead of five); its first
-// two passes write index 8j + r and 64 (j >> 3) + (j & 7) + 8r, for which the slot is XOR-ed with (i3, i4, i5).
+// Lengths 512 / 1024 / 2048 (grids 256^2, 512^2, 1024^2) start with radix-8 passes (FFT_R8): plans 8x8x8, 8x8x4x4 and
+// 8x8x8x4, i.e. 3 / 4 / 4 LDS exchanges instead of 5 / 5 / 6.  Those passes write index 8j + r, 64 (j >> 3) + (j & 7) + 8r,
+// 512 (j >> 6) + (j & 63) + 64r, for which the slot is XOR-ed with (i3, i4, i5).
 #ifndef FFT_R8
 #define FFT_R8 1
 #endif
 template <int LOGL>
 __device__ __forceinline__ int swz(int c) {
 #if FFT_R8 && FFT_SWZ && !FFT_PAD
-    if (LOGL == 10) return c ^ ((c >> 3) & 7);
+    if (LOGL >= 9 && LOGL <= 11) return c ^ ((c >> 3) & 7);
 #endif
     return PADC(c);
 }
@@ -103,18 +104,20 @@ __device__ __forceinline__ void fft_lds(double2 *buf, const FftAxis ax) {
     const int logL = LOGL ? LOGL : ax.logL, L = 1 << logL;
     int logNs = 0;
 #if FFT_R8
-    if (LOGL == 10) {
-        // two radix-8 passes (Ns = 1, 8): C/8 butterflies = one per thread (C = 1024, T = 128)
-        static_assert(LOGL != 10 || C == 8 * T, "radix-8 plan: one butterfly per thread");
+    if (LOGL >= 9 && LOGL <= 11) {
+        // leading radix-8 passes (Ns = 1, 8[, 64]): C/8 butterflies = one per thread (T = C/8)
+        static_assert(LOGL < 9 || LOGL > 11 || C == 8 * T, "radix-8 plan: one butterfly per thread");
+        constexpr int NR8 = LOGL == 10 ? 2 : 3;
         constexpr double RH = 0.70710678118654752440;
+        const int f = tid >> (logL - 3), j = tid & ((L >> 3) - 1), fb = f * L;
 #pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
-            const int Ns = ps ? 8 : 1, j = tid, k = j & (Ns - 1);
+        for (int ps = 0; ps < NR8; ++ps) {
+            const int lNs = 3 * ps, Ns = 1 << lNs, k = j & (Ns - 1);
             double2 a[8];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) a[r] = buf[swz<LOGL>(j + r * (L >> 3))];
-            if (ps) {                                   // inputs r = 1..7 times w^r, w = exp(-2 pi i k / 64)
-                const double2 w1 = ax.tw[k << 4];
+            for (int r = 0; r < 8; ++r) a[r] = buf[swz<LOGL>(fb + j + r * (L >> 3))];
+            if (ps) {                                   // inputs r = 1..7 times w^r, w = exp(-2 pi i k / (8 Ns))
+                const double2 w1 = ax.tw[k << (logL - 3 - lNs)];
                 double2 w = w1;
                 a[1] = cmul(a[1], w);
 #pragma unroll
@@ -145,13 +148,13 @@ __device__ __forceinline__ void fft_lds(double2 *buf, const FftAxis ax) {
                 o[h + 4] = make_double2(t0.x - t2.x, t0.y - t2.y);
                 o[h + 6] = make_double2(t1.x - t3.x, t1.y - t3.y);
             }
-            const int wb = ((j >> (3 * ps)) << (3 * ps + 3)) + k;
+            const int wb = fb + ((j >> lNs) << (lNs + 3)) + k;
             __syncthreads();
 #pragma unroll
             for (int r = 0; r < 8; ++r) buf[swz<LOGL>(wb + r * Ns)] = o[r];
             __syncthreads();
         }
-        logNs = 6;
+        logNs = 3 * NR8;
     }
 #endif
     // radix-4 passes: C/4 butterflies = 4 per thread
@@ -395,7 +398,7 @@ __device__ __forceinline__ void dcth_pre(double2 *buf, const FftAxis &axL, int f
         const double2 t = axL.tw[n];                     // exp(-i pi n / N): cos = t.x, sin = -t.y
         const double ya = 0.5 * (xa[j] + ma[j]) + t.y * (xa[j] - ma[j]);
         const double yb = 0.5 * (xb[j] + mb[j]) + t.y * (xb[j] - mb[j]);
-        buf[PADC(f * HN + n)] = make_double2(ya, yb);
+        buf[swz<HLOGN>(f * HN + n)] = make_double2(ya, yb);
         if (n == 0) {
             sa += 0.5 * (xa[j] - ma[j]);
             sb += 0.5 * (xb[j] - mb[j]);
@@ -415,7 +418,7 @@ __device__ __forceinline__ void dcth_post(const double2 *buf, int f, int l, doub
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int k = 4 * l + j;
-        const double2 zk = buf[PADC(f * HN + k)], zm = buf[PADC(f * HN + ((HN - k) & (HN - 1)))];
+        const double2 zk = buf[swz<HLOGN>(f * HN + k)], zm = buf[swz<HLOGN>(f * HN + ((HN - k) & (HN - 1)))];
         ea[2 * j] = 0.5 * (zk.x + zm.x);                 // Re Y_a
         eb[2 * j] = 0.5 * (zk.y + zm.y);                 // Re Y_b
         da[j] = k == 0 ? 0.0 : -0.5 * (zk.y - zm.y);     // -Im Y_a
@@ -432,7 +435,7 @@ __device__ __forceinline__ void dcth_post(const double2 *buf, int f, int l, doub
         ea[2 * j + 1] = oa + da[j];
         eb[2 * j + 1] = ob + db[j];
     }
-    const double2 zh = buf[PADC(f * HN + HN / 2)];
+    const double2 zh = buf[swz<HLOGN>(f * HN + HN / 2)];
     eNa = zh.x;
     eNb = zh.y;
 #pragma unroll
