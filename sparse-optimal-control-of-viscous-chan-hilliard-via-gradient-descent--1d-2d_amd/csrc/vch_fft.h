@@ -71,6 +71,9 @@ __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
 #ifndef FFT_R8
 #define FFT_R8 1
 #endif
+#ifndef FFT_COLS_EMIT
+#define FFT_COLS_EMIT 1
+#endif
 template <int LOGL>
 __device__ __forceinline__ int swz(int c) {
 #if FFT_R8 && FFT_SWZ && !FFT_PAD
@@ -96,8 +99,19 @@ struct FftThreads {
 
 // LOGL > 0: log2 of the FFT length is a compile-time constant (all index arithmetic folds and the
 // pass loop unrolls; the kernels are VALU-issue bound, so this matters); LOGL = 0: run-time length.
-template <int C, int LOGL>
-__device__ __forceinline__ void fft_lds(double2 *buf, const FftAxis ax) {
+//
+// Emit: what happens to the outputs of the LAST pass (compile-time lengths 512 / 1024 / 2048 only).  Default: they go
+// back into the image like those of every other pass.  Otherwise emit(index in the image, value) is called for each
+// output instead -- the kernels store the wanted half of the spectrum straight to global memory (Emit::TO_LDS = 0: no
+// barriers at all around the last pass) or write it back scaled (TO_LDS = 1: the spectral multiplier costs no pass).
+struct FftNoEmit {
+    static constexpr int ACTIVE = 0, TO_LDS = 1;
+    __device__ __forceinline__ void operator()(int, double2) const {}
+};
+
+template <int C, int LOGL, class Emit = FftNoEmit>
+__device__ __forceinline__ void fft_lds(double2 *buf, const FftAxis ax, Emit emit = Emit()) {
+    constexpr bool EMIT = Emit::ACTIVE && LOGL >= 9 && LOGL <= 11 && FFT_R8;
     constexpr int T = FftThreads<C>::T;
     constexpr int NB4 = C / (4 * T), NB2 = C / (2 * T);
     const int tid = threadIdx.x;
@@ -149,10 +163,17 @@ __device__ __forceinline__ void fft_lds(double2 *buf, const FftAxis ax) {
                 o[h + 6] = make_double2(t1.x - t3.x, t1.y - t3.y);
             }
             const int wb = fb + ((j >> lNs) << (lNs + 3)) + k;
-            __syncthreads();
+            if (EMIT && 3 * (ps + 1) == LOGL) {          // last pass of the 8x8x8 plan
+                if (Emit::TO_LDS) __syncthreads();
 #pragma unroll
-            for (int r = 0; r < 8; ++r) buf[swz<LOGL>(wb + r * Ns)] = o[r];
-            __syncthreads();
+                for (int r = 0; r < 8; ++r) emit(wb + r * Ns, o[r]);
+                if (Emit::TO_LDS) __syncthreads();
+            } else {
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < 8; ++r) buf[swz<LOGL>(wb + r * Ns)] = o[r];
+                __syncthreads();
+            }
         }
         logNs = 3 * NR8;
     }
@@ -201,12 +222,21 @@ __device__ __forceinline__ void fft_lds(double2 *buf, const FftAxis ax) {
             v[i][3] = make_double2(t1.x - t3.x, t1.y - t3.y);
             wbase[i] = f * L + ((j >> logNs) << (logNs + 2)) + k;
         }
-        __syncthreads();
+        if (EMIT && logNs + 2 == logL) {
+            if (Emit::TO_LDS) __syncthreads();
 #pragma unroll
-        for (int i = 0; i < NB4; ++i)
+            for (int i = 0; i < NB4; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) buf[swz<LOGL>(wbase[i] + r * Ns)] = v[i][r];
-        __syncthreads();
+                for (int r = 0; r < 4; ++r) emit(wbase[i] + r * Ns, v[i][r]);
+            if (Emit::TO_LDS) __syncthreads();
+        } else {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < NB4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) buf[swz<LOGL>(wbase[i] + r * Ns)] = v[i][r];
+            __syncthreads();
+        }
     }
     if (logNs < logL) {          // one radix-2 pass: C/2 butterflies = 8 per thread
         const int Ns = 1 << logNs, H = L >> 1, logH = logL - 1;
@@ -260,8 +290,6 @@ __global__ __launch_bounds__(FftThreads<C>::T) void k_dct_rows(Geom G, FftAxis a
     }
     __syncthreads();
     FFT_STAMP(1);
-    fft_lds<C, LOGL>(buf, ax);
-    FFT_STAMP(2);
     double dot = 0.0, dot2 = 0.0, dbar = 0.0;
     const double *Dp = nullptr, *Ob = nullptr;
     if (EPI == 3) {
@@ -270,18 +298,45 @@ __global__ __launch_bounds__(FftThreads<C>::T) void k_dct_rows(Geom G, FftAxis a
         Ob = sp.other ? sp.other + b * G.plane : nullptr;
     }
     double *ob = out + b * G.plane;
-    for (int idx = tid; idx < 2 * nfft * n1; idx += T) {
-        const int rr = nfft == 1 ? (idx >= n1 ? 1 : 0) : (int)(((float)idx + 0.5f) * inv_n1), k = idx - rr * n1;
-        const int row = row0 + rr;
-        if (row < G.ns) {
-            const double2 c = buf[swz<LOGL>((rr >> 1) * L + k)];
-            const double v = scale * ((rr & 1) ? c.y : c.x);
-            const long o = (long)row * G.pitch + k;
-            ob[o] = v;
-            if (EPI == 3) {
-                const double wd = wdev(row, k, G) * (Dp[o] - dbar);
-                dot += wd * ((Ob ? Ob[o] : v) * v);
-                dot2 += wd * (v * v);
+    auto put = [&](int row, int k, double e) {
+        const double v = scale * e;
+        const long o = (long)row * G.pitch + k;
+        ob[o] = v;
+        if (EPI == 3) {
+            const double wd = wdev(row, k, G) * (Dp[o] - dbar);
+            dot += wd * ((Ob ? Ob[o] : v) * v);
+            dot2 += wd * (v * v);
+        }
+    };
+    constexpr bool DIRECT = FFT_R8 && LOGL >= 9 && LOGL <= 11;
+    if (DIRECT) {
+        // the last pass hands its outputs over in registers: entry k <= N of transform f is (E(a)_k, E(b)_k) of rows
+        // row0 + 2f, row0 + 2f + 1 (the upper half of the spectrum is its mirror image and is dropped)
+        struct RowEmit {
+            enum { ACTIVE = 1, TO_LDS = 0 };
+            decltype(put) &put_;
+            int row0_, ns_;
+            __device__ __forceinline__ void operator()(int idx, double2 v) const {
+                constexpr int LL = 1 << (LOGL ? LOGL : 1);
+                const int f = idx >> (LOGL ? LOGL : 1), k = idx & (LL - 1);
+                if (k <= LL / 2) {
+                    const int ra = row0_ + 2 * f;
+                    if (ra < ns_) put_(ra, k, v.x);
+                    if (ra + 1 < ns_) put_(ra + 1, k, v.y);
+                }
+            }
+        };
+        fft_lds<C, LOGL>(buf, ax, RowEmit{put, row0, G.ns});
+        FFT_STAMP(2);
+    } else {
+        fft_lds<C, LOGL>(buf, ax);
+        FFT_STAMP(2);
+        for (int idx = tid; idx < 2 * nfft * n1; idx += T) {
+            const int rr = nfft == 1 ? (idx >= n1 ? 1 : 0) : (int)(((float)idx + 0.5f) * inv_n1), k = idx - rr * n1;
+            const int row = row0 + rr;
+            if (row < G.ns) {
+                const double2 c = buf[swz<LOGL>((rr >> 1) * L + k)];
+                put(row, k, (rr & 1) ? c.y : c.x);
             }
         }
     }
@@ -334,22 +389,66 @@ __global__ __launch_bounds__(FftThreads<C>::T) void k_dct_cols(Geom G, FftAxis a
         if (r > 0 && r < N) sb[2 * swz<LOGL>(f * L + L - r) + comp] = v;
     }
     __syncthreads();
-    fft_lds<C, LOGL>(buf, ax);
     const double c1 = sp.c1a + sp.c1b * st[b].dbar;
-    for (int idx = tid; idx < nfft * L; idx += T) {
-        const int f = idx >> logL, k = idx & (L - 1);
-        const int ks = k <= N ? k : L - k;
-        const int ca = col0 + 2 * f, cb = ca + 1;
-        const double msk = sp.ms[ks];
-        double2 v = buf[swz<LOGL>(idx)];
-        double ma = msk + sp.mf[ca < G.nf ? ca : G.nf - 1], mb = msk + sp.mf[cb < G.nf ? cb : G.nf - 1];
-        v.x *= scale / (sp.c0 + ma * (c1 + sp.c2 * ma));
-        v.y *= scale / (sp.c0 + mb * (c1 + sp.c2 * mb));
-        buf[swz<LOGL>(idx)] = v;
-    }
-    __syncthreads();
-    fft_lds<C, LOGL>(buf, ax);
     double *ob = out + b * G.plane;
+    constexpr bool DIRECT = FFT_R8 && LOGL >= 9 && LOGL <= 11;
+    constexpr int LL = 1 << (LOGL ? LOGL : 1), LG = LOGL ? LOGL : 1;
+    // forward transform; with a compile-time plan its last pass writes the outputs back already multiplied by the
+    // spectral multiplier (FFT_COLS_EMIT & 1), otherwise a separate pass over the image does
+    struct ScaleEmit {
+        enum { ACTIVE = 1, TO_LDS = 1 };
+        double2 *buf_;
+        const SpecArgs &sp_;
+        double c1_, scale_;
+        int col0_, nf_;
+        __device__ __forceinline__ void operator()(int idx, double2 v) const {
+            const int f = idx >> LG, k = idx & (LL - 1), ks = k <= LL / 2 ? k : LL - k;
+            const int ca = col0_ + 2 * f, cb = ca + 1;
+            const double msk = sp_.ms[ks];
+            const double ma = msk + sp_.mf[ca < nf_ ? ca : nf_ - 1], mb = msk + sp_.mf[cb < nf_ ? cb : nf_ - 1];
+            v.x *= scale_ / (sp_.c0 + ma * (c1_ + sp_.c2 * ma));
+            v.y *= scale_ / (sp_.c0 + mb * (c1_ + sp_.c2 * mb));
+            buf_[swz<LOGL>(idx)] = v;
+        }
+    };
+    if (DIRECT && (FFT_COLS_EMIT & 1)) {
+        fft_lds<C, LOGL>(buf, ax, ScaleEmit{buf, sp, c1, scale, col0, G.nf});
+    } else {
+        fft_lds<C, LOGL>(buf, ax);
+        for (int idx = tid; idx < nfft * L; idx += T) {
+            const int f = idx >> logL, k = idx & (L - 1);
+            const int ks = k <= N ? k : L - k;
+            const int ca = col0 + 2 * f, cb = ca + 1;
+            const double msk = sp.ms[ks];
+            double2 v = buf[swz<LOGL>(idx)];
+            double ma = msk + sp.mf[ca < G.nf ? ca : G.nf - 1], mb = msk + sp.mf[cb < G.nf ? cb : G.nf - 1];
+            v.x *= scale / (sp.c0 + ma * (c1 + sp.c2 * ma));
+            v.y *= scale / (sp.c0 + mb * (c1 + sp.c2 * mb));
+            buf[swz<LOGL>(idx)] = v;
+        }
+        __syncthreads();
+    }
+    // second transform; the wanted half of its last pass's outputs can go straight to global memory (FFT_COLS_EMIT & 2)
+    struct ColEmit {
+        enum { ACTIVE = 1, TO_LDS = 0 };
+        double *ob_;
+        long pitch_;
+        int col0_, nf_;
+        __device__ __forceinline__ void operator()(int idx, double2 v) const {
+            const int f = idx >> LG, k = idx & (LL - 1);
+            if (k <= LL / 2) {
+                const int ca = col0_ + 2 * f;
+                double *po = ob_ + (long)k * pitch_ + ca;
+                if (ca < nf_) po[0] = v.x;
+                if (ca + 1 < nf_) po[1] = v.y;
+            }
+        }
+    };
+    if (DIRECT && (FFT_COLS_EMIT & 2)) {
+        fft_lds<C, LOGL>(buf, ax, ColEmit{ob, (long)G.pitch, col0, G.nf});
+        return;
+    }
+    fft_lds<C, LOGL>(buf, ax);
     for (int idx = tid; idx < n1 * ncol; idx += T) {
         const int r = idx >> lc, cc = idx & (ncol - 1);
         const int col = col0 + cc;
