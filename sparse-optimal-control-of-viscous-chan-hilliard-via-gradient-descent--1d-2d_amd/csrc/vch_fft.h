@@ -71,6 +71,12 @@ __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
 #ifndef FFT_R8
 #define FFT_R8 1
 #endif
+#ifndef FFT_ROWS_INGEST
+#define FFT_ROWS_INGEST 1
+#endif
+#ifndef FFT_COLS_INGEST
+#define FFT_COLS_INGEST 0
+#endif
 #ifndef FFT_COLS_EMIT
 #define FFT_COLS_EMIT 1
 #endif
@@ -109,9 +115,18 @@ struct FftNoEmit {
     __device__ __forceinline__ void operator()(int, double2) const {}
 };
 
-template <int C, int LOGL, class Emit = FftNoEmit>
-__device__ __forceinline__ void fft_lds(double2 *buf, const FftAxis ax, Emit emit = Emit()) {
+// Ingest: where the FIRST pass takes its inputs from (same lengths).  Default: the image.  Otherwise ingest(index in the
+// image) supplies them -- the kernels read global memory directly, so the image is never staged (no fill loop, no barrier
+// before the first pass).
+struct FftNoIngest {
+    enum { ACTIVE = 0 };
+    __device__ __forceinline__ double2 operator()(int) const { return make_double2(0.0, 0.0); }
+};
+
+template <int C, int LOGL, class Emit = FftNoEmit, class Ingest = FftNoIngest>
+__device__ __forceinline__ void fft_lds(double2 *buf, const FftAxis ax, Emit emit = Emit(), Ingest ingest = Ingest()) {
     constexpr bool EMIT = Emit::ACTIVE && LOGL >= 9 && LOGL <= 11 && FFT_R8;
+    constexpr bool INGEST = Ingest::ACTIVE && LOGL >= 9 && LOGL <= 11 && FFT_R8;
     constexpr int T = FftThreads<C>::T;
     constexpr int NB4 = C / (4 * T), NB2 = C / (2 * T);
     const int tid = threadIdx.x;
@@ -129,7 +144,8 @@ __device__ __forceinline__ void fft_lds(double2 *buf, const FftAxis ax, Emit emi
             const int lNs = 3 * ps, Ns = 1 << lNs, k = j & (Ns - 1);
             double2 a[8];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) a[r] = buf[swz<LOGL>(fb + j + r * (L >> 3))];
+            for (int r = 0; r < 8; ++r)
+                a[r] = (INGEST && ps == 0) ? ingest(fb + j + r * (L >> 3)) : buf[swz<LOGL>(fb + j + r * (L >> 3))];
             if (ps) {                                   // inputs r = 1..7 times w^r, w = exp(-2 pi i k / (8 Ns))
                 const double2 w1 = ax.tw[k << (logL - 3 - lNs)];
                 double2 w = w1;
@@ -169,7 +185,7 @@ __device__ __forceinline__ void fft_lds(double2 *buf, const FftAxis ax, Emit emi
                 for (int r = 0; r < 8; ++r) emit(wb + r * Ns, o[r]);
                 if (Emit::TO_LDS) __syncthreads();
             } else {
-                __syncthreads();
+                if (!(INGEST && ps == 0)) __syncthreads();          // nobody has read the image yet in an ingesting first pass
 #pragma unroll
                 for (int r = 0; r < 8; ++r) buf[swz<LOGL>(wb + r * Ns)] = o[r];
                 __syncthreads();
@@ -280,15 +296,18 @@ __global__ __launch_bounds__(FftThreads<C>::T) void k_dct_rows(Geom G, FftAxis a
     const int n1 = N + 1;
     const float inv_n1 = 1.0f / (float)n1;       // idx < 2^14: the float quotient is exact enough
     FFT_STAMP(0);
-    for (int idx = tid; idx < nfft * n1; idx += T) {
-        const int f = nfft == 1 ? 0 : (int)(((float)idx + 0.5f) * inv_n1), j = idx - f * n1;
-        const int ra = row0 + 2 * f, rb = ra + 1;
-        double2 v = make_double2(ra < G.ns ? ib[(long)ra * G.pitch + j] : 0.0,
-                                 rb < G.ns ? ib[(long)rb * G.pitch + j] : 0.0);
-        buf[swz<LOGL>(f * L + j)] = v;
-        if (j > 0 && j < N) buf[swz<LOGL>(f * L + L - j)] = v;
+    constexpr bool DIRECT = FFT_R8 && LOGL >= 9 && LOGL <= 11;
+    if (!(DIRECT && FFT_ROWS_INGEST)) {
+        for (int idx = tid; idx < nfft * n1; idx += T) {
+            const int f = nfft == 1 ? 0 : (int)(((float)idx + 0.5f) * inv_n1), j = idx - f * n1;
+            const int ra = row0 + 2 * f, rb = ra + 1;
+            double2 v = make_double2(ra < G.ns ? ib[(long)ra * G.pitch + j] : 0.0,
+                                     rb < G.ns ? ib[(long)rb * G.pitch + j] : 0.0);
+            buf[swz<LOGL>(f * L + j)] = v;
+            if (j > 0 && j < N) buf[swz<LOGL>(f * L + L - j)] = v;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     FFT_STAMP(1);
     double dot = 0.0, dot2 = 0.0, dbar = 0.0;
     const double *Dp = nullptr, *Ob = nullptr;
@@ -308,7 +327,6 @@ __global__ __launch_bounds__(FftThreads<C>::T) void k_dct_rows(Geom G, FftAxis a
             dot2 += wd * (v * v);
         }
     };
-    constexpr bool DIRECT = FFT_R8 && LOGL >= 9 && LOGL <= 11;
     if (DIRECT) {
         // the last pass hands its outputs over in registers: entry k <= N of transform f is (E(a)_k, E(b)_k) of rows
         // row0 + 2f, row0 + 2f + 1 (the upper half of the spectrum is its mirror image and is dropped)
@@ -326,7 +344,22 @@ __global__ __launch_bounds__(FftThreads<C>::T) void k_dct_rows(Geom G, FftAxis a
                 }
             }
         };
-        fft_lds<C, LOGL>(buf, ax, RowEmit{put, row0, G.ns});
+        // ... and the first pass takes its inputs (entry i of the even extension of rows row0 + 2f, + 1) from global memory
+        struct RowIngest {
+            enum { ACTIVE = 1 };
+            const double *ib_;
+            long pitch_;
+            int row0_, ns_;
+            __device__ __forceinline__ double2 operator()(int idx) const {
+                constexpr int LL = 1 << (LOGL ? LOGL : 1);
+                const int f = idx >> (LOGL ? LOGL : 1), i = idx & (LL - 1), m = i <= LL / 2 ? i : LL - i;
+                const int ra = row0_ + 2 * f;
+                const double *p = ib_ + (long)ra * pitch_ + m;
+                return make_double2(ra < ns_ ? p[0] : 0.0, ra + 1 < ns_ ? p[pitch_] : 0.0);
+            }
+        };
+        if (FFT_ROWS_INGEST) fft_lds<C, LOGL>(buf, ax, RowEmit{put, row0, G.ns}, RowIngest{ib, (long)G.pitch, row0, G.ns});
+        else fft_lds<C, LOGL>(buf, ax, RowEmit{put, row0, G.ns});
         FFT_STAMP(2);
     } else {
         fft_lds<C, LOGL>(buf, ax);
@@ -380,19 +413,34 @@ __global__ __launch_bounds__(FftThreads<C>::T) void k_dct_cols(Geom G, FftAxis a
     const int n1 = N + 1;
     int lc = 0;                                   // log2(ncol)
     while ((1 << lc) < ncol) ++lc;
-    for (int idx = tid; idx < n1 * ncol; idx += T) {
-        const int r = idx >> lc, cc = idx & (ncol - 1);
-        const int col = col0 + cc;
-        const double v = col < G.nf ? ib[(long)r * G.pitch + col] : 0.0;
-        const int f = cc >> 1, comp = cc & 1;
-        sb[2 * swz<LOGL>(f * L + r) + comp] = v;
-        if (r > 0 && r < N) sb[2 * swz<LOGL>(f * L + L - r) + comp] = v;
-    }
-    __syncthreads();
-    const double c1 = sp.c1a + sp.c1b * st[b].dbar;
-    double *ob = out + b * G.plane;
     constexpr bool DIRECT = FFT_R8 && LOGL >= 9 && LOGL <= 11;
     constexpr int LL = 1 << (LOGL ? LOGL : 1), LG = LOGL ? LOGL : 1;
+    if (!(DIRECT && FFT_COLS_INGEST && (FFT_COLS_EMIT & 1))) {
+        for (int idx = tid; idx < n1 * ncol; idx += T) {
+            const int r = idx >> lc, cc = idx & (ncol - 1);
+            const int col = col0 + cc;
+            const double v = col < G.nf ? ib[(long)r * G.pitch + col] : 0.0;
+            const int f = cc >> 1, comp = cc & 1;
+            sb[2 * swz<LOGL>(f * L + r) + comp] = v;
+            if (r > 0 && r < N) sb[2 * swz<LOGL>(f * L + L - r) + comp] = v;
+        }
+        __syncthreads();
+    }
+    // first pass of the forward transform fed from global memory: entry i of the even extension of columns col0 + 2f, + 1
+    struct ColIngest {
+        enum { ACTIVE = 1 };
+        const double *ib_;
+        long pitch_;
+        int col0_, nf_;
+        __device__ __forceinline__ double2 operator()(int idx) const {
+            const int f = idx >> LG, i = idx & (LL - 1), m = i <= LL / 2 ? i : LL - i;
+            const int ca = col0_ + 2 * f;
+            const double *p = ib_ + (long)m * pitch_ + ca;
+            return make_double2(ca < nf_ ? p[0] : 0.0, ca + 1 < nf_ ? p[1] : 0.0);
+        }
+    };
+    const double c1 = sp.c1a + sp.c1b * st[b].dbar;
+    double *ob = out + b * G.plane;
     // forward transform; with a compile-time plan its last pass writes the outputs back already multiplied by the
     // spectral multiplier (FFT_COLS_EMIT & 1), otherwise a separate pass over the image does
     struct ScaleEmit {
@@ -412,7 +460,10 @@ __global__ __launch_bounds__(FftThreads<C>::T) void k_dct_cols(Geom G, FftAxis a
         }
     };
     if (DIRECT && (FFT_COLS_EMIT & 1)) {
-        fft_lds<C, LOGL>(buf, ax, ScaleEmit{buf, sp, c1, scale, col0, G.nf});
+        if (FFT_COLS_INGEST)
+            fft_lds<C, LOGL>(buf, ax, ScaleEmit{buf, sp, c1, scale, col0, G.nf}, ColIngest{ib, (long)G.pitch, col0, G.nf});
+        else
+            fft_lds<C, LOGL>(buf, ax, ScaleEmit{buf, sp, c1, scale, col0, G.nf});
     } else {
         fft_lds<C, LOGL>(buf, ax);
         for (int idx = tid; idx < nfft * L; idx += T) {
