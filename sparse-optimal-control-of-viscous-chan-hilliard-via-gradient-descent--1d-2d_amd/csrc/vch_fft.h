@@ -9,14 +9,15 @@
 //
 // A workgroup of C/8 threads owns an LDS image of C complex doubles = NFFT = C/L transforms
 // (2 NFFT rows or columns of the plane); C = 1024 for L <= 1024, i.e. TWO wavefronts and 16 KiB
-// of LDS per workgroup, so ~10 independent workgroups (20 waves) share a CU and hide each other's
-// global-memory and LDS latency (C = 2048 / 4096 for L = 2048 / 4096).  Measured on MI355X at
-// 512^2 x 8 (profiles/r01_c_fft_variants.txt): the kernels are latency-bound, not bank-conflict
-// bound -- 2 waves per transform beat 1 and 4, padding the image (fewer resident workgroups) and
-// writing the last pass straight to global memory (narrower stores) both lose.  The FFT is a radix-4
-// Stockham autosort (plus one radix-2 pass when log2 L is odd), done in place: every thread
-// reads its 4 x 4 operands, barrier, writes them back transposed, barrier.  Twiddles come from a table of
-// exp(-2 pi i m / L) computed in long double on the host.
+// of LDS per workgroup, so ~10 independent workgroups (20 waves) share a CU (C = 2048 / 4096 for L = 2048 / 4096).
+// The FFT is a Stockham autosort done in place: every thread reads its operands, barrier, writes them back
+// transposed, barrier.  Measured on MI355X at 512^2 x 8 (profiles/r01_c_fft_variants.txt, r01_i_fft_phases.txt) a
+// pass kernel is bound by this chain of barrier-separated phases, so the plans minimise their number:
+//   * lengths 512 / 1024 / 2048 start with radix-8 passes (one butterfly per thread): 8x8x8, 8x8x4x4, 8x8x8x4;
+//     other lengths radix-4 (plus one radix-2 pass when log2 L is odd);
+//   * the first pass can take its inputs from global memory (Ingest) and the last pass can hand its outputs over
+//     in registers (Emit) instead of going through the image.
+// Twiddles come from a table of exp(-2 pi i m / L) computed in long double on the host.
 //
 //   k_dct_rows : E along the fast (contiguous) axis for 2 NFFT rows; optional epilogue
 //                (weighted dot partial for the CG scalars)
