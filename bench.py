@@ -9,20 +9,25 @@ steps, batch of 64 random initial conditions sharded over 8 GPUs = 8 trajectorie
 
 A "step" is one proximal-gradient iteration for every trajectory of the batch = one pass of
 the reference's loop body (GD2_configured.py:295-382): adjoint sweep (1000 linear solves) +
-gradient/soft-threshold prox + forward march (1000 Newton solves) + cost (+ backtracking
-forwards when the optimistic step fails).  Inputs are resident in HBM when the timed region
-starts.  `value` = trajectory-iterations per second over all ranks.
+gradient/soft-threshold prox + forward march (1000 Newton solves) + cost + error metrics
+(+ backtracking forwards when the optimistic step fails).  Inputs are resident in HBM when the
+timed region starts.  `value` = trajectory-iterations per second over all ranks (batch x
+iterations / s; the batch advances in lock step, so batch-iterations/s = value / batch).
 
 The one collective of the data path is a single RCCL all-reduce of the cost scalars per step
-(10*B doubles); trajectories are independent.
+(SURVEY 8e), issued through the C ABI on the device-resident scalars (vch_comm_allreduce_cost;
+`--collective torch` uses torch.distributed on a host copy instead).
 
 One JSON line is printed by rank 0.  Extra objects:
-  roofline      in-situ HIP-event timing of the dominant kernel class (one extra, untimed PGD
-                iteration with an event pair around each launch of the profiled kernels)
+  roofline      the dominant kernel: algorithmic bytes per launch / mean launch duration, measured with HIP
+                event pairs on the engine's stream(s) during ONE extra PGD iteration in which every context
+                of the rank runs (the same contention as the timed region); `roofline_kernels` lists every
+                profiled kernel the same way, `roofline_newton_stencil` is the north-star kernel
   cpu_baseline  the CPU oracle (numpy/scipy restatement of the reference, SuperLU solves) timed
-                on this box's host cores on a bounded sample of the same workload
+                on this box's host cores on a bounded sample of the same workload (rank 0, N = 1)
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -37,6 +42,19 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_MFMA_PEAK_TF = 78.6     # = 1/2 of the 157.3 TF FP32 vector/matrix peak of the same table
                              # (v_mfma_f64_16x16x4_f64 issues at the FP64 vector rate on gfx950)
 
+# Algorithmic bytes per node per launch (fp64 fields read + written once).
+ALG_BYTES = {
+    "schur_p": 72.0,         # z, q, p_old, D, x -> x, z', p, v
+    "schur_p_first": 40.0,   # z, D -> x (zeroed), p, v
+    "dct_rows_fwd": 16.0,    # field -> field
+    "dct_cols": 16.0,        # field -> field (forward transform, multiplier, inverse transform in LDS)
+    "dct_rows_inv": 32.0,    # field, D, other -> field (+ the CG dot products)
+    "residual": 88.0,        # trial form: phi, dphi, mu, dmu, c_phi, c_mu -> phi_t, mu_t, R_phi, rhs, D
+    "adj_q": 32.0, "cg_update": 48.0, "adj_rhs": 72.0,
+}
+PMC_NAMES = {"schur_p": "k_schur_p<0>", "dct_rows_fwd": "k_dct_rows<0, 1024, 10>", "dct_cols": "k_dct_cols<1024, 10>",
+             "dct_rows_inv": "k_dct_rows<3, 1024, 10>", "residual": "k_residual<1>", "adj_q": "k_adj_q"}
+
 
 def parse():
     ap = argparse.ArgumentParser()
@@ -48,49 +66,70 @@ def parse():
     ap.add_argument("--batch-per-gpu", type=int, default=8)
     ap.add_argument("--contexts", type=int, default=2,
                     help="engine contexts (HIP streams, one host thread each) the per-GPU batch is split over")
+    ap.add_argument("--collective", choices=["cabi", "torch"], default="cabi")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-grid", type=int, default=None, help="grid of the CPU sample (default: --grid)")
+    ap.add_argument("--cpu-steps", type=int, default=3, help="forward and adjoint time steps of the CPU sample")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="tests only: gloo + a stand-in engine, exercises the multi-rank skeleton without a GPU")
+    ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help="tests only: this rank's stand-in engine raises")
     return ap.parse_args()
 
 
-def cpu_baseline(N, dt, M):
-    """Bounded CPU sample with the oracle (kind 'port'): at the full spatial size, one adjoint
-    time step (assemble + SuperLU solve of A(phi_n)) and one Newton linear solve of a forward
-    step (assemble + SuperLU solve of the 2x2-block Jacobian), single trajectory; a PGD
-    iteration is extrapolated linearly in the step count with 2 Newton solves per forward step
-    (the reference's own count at 512^2, tests/golden/g2d_newton_512.npz)."""
-    import scipy.sparse as sp
-    from scipy.sparse.linalg import spsolve
+def cpu_baseline(N, dt, M, n_steps):
+    """Bounded CPU sample with the oracle (kind 'port'): `n_steps` forward time steps (Newton with SuperLU solves of
+    the 2x2-block Jacobian, F2:323-427) and `n_steps` adjoint steps (assemble + SuperLU solve of A(phi_n), B2:212-242)
+    at the full spatial size, one trajectory, one wall-time sample per step; the once-per-march assembly of L and L@L
+    is outside the samples.  A PGD iteration (no backtracking) is extrapolated linearly in the step count."""
     from oracle import vch2d_oracle as O2
-    P = O2.Params2D(Nx=N, Ny=N, T=dt * M, dt_initial=dt)
-    h = 1.0 / N
-    phi = O2.init_phi_random(N, N, 1e-2, amp=0.1, seed=42)
-    w = np.zeros_like(phi)
-    t0 = time.perf_counter()
-    L = O2.lap_matrix(N, N, h, h)
-    mu = O2.mu_init(phi, w, P, h, h)
-    Rp = O2.residual_phi(phi, phi, mu, mu, w, w, dt, P, h, h)
-    Rm = O2.residual_mu(phi, phi, mu, mu, dt, h, h)
-    J = O2.jac_matrix(phi, dt, P, L)
-    spsolve(J.tocsc(), -np.concatenate([Rp.ravel(), Rm.ravel()]))
-    t_newton = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    n = phi.size
-    I = sp.identity(n, format="csr")
-    LL = (L @ L).tocsr()
-    Dn = sp.diags(O2.fpp(phi.ravel(), P.c1, P.c2), 0, format="csr")
-    A = (I - P.tau * L + 0.5 * dt * LL - 0.5 * dt * (Dn @ L)).tocsc()
-    Bm = (I - P.tau * L - 0.5 * dt * LL + 0.5 * dt * (Dn @ L)).tocsr()
-    spsolve(A, Bm @ phi.ravel())
-    t_adj = time.perf_counter() - t0
-    solves_per_step = 2.0
-    per_iter = M * (t_adj + solves_per_step * t_newton)
+    r = O2.time_one_step(N, dt, n_fwd_steps=n_steps, n_bwd_steps=n_steps)
+    per_iter = M * (r["fwd_s_per_step"] + r["bwd_s_per_step"])
     return dict(value=1.0 / per_iter, unit="PGD iterations/s", cores=1, kind="port",
-                sample=(f"oracle (scipy SuperLU, serial) at {N}x{N}: 1 Newton linear solve {t_newton:.1f} s + "
-                        f"1 adjoint step {t_adj:.1f} s, 1 trajectory; extrapolated to {M} steps x "
-                        f"(1 adjoint + {solves_per_step:g} Newton solves)"),
-                newton_solve_s=t_newton, adjoint_step_s=t_adj)
+                sample=(f"oracle (scipy SuperLU, serial) at {N}x{N}, 1 trajectory: {r['fwd_steps']} forward steps "
+                        f"({r['solves']} Newton solves) + {r['bwd_steps']} adjoint steps, one sample per step; "
+                        f"extrapolated to {M} x (1 forward + 1 adjoint step), no backtracking"),
+                fwd_step_seconds=r["fwd_step_seconds"], bwd_step_seconds=r["bwd_step_seconds"])
+
+
+def source_hash():
+    import importlib
+    import vch_amd
+    L = importlib.import_module(vch_amd.PKG_NAME + "._lib")
+    return L.source_hash()
+
+
+class DryEngine:
+    """Stand-in for Engine2D in --dry-run (tests of the multi-rank skeleton on CPU): same methods, no arithmetic."""
+    uses_fft = True
+    PROF_CLASSES = ()
+
+    def __init__(self, batch, fail=False):
+        self.B, self.k, self.ctx, self.fail = batch, 0, None, fail
+
+    def pgd_init(self, phi0, *a, **k):
+        return np.ones((self.B, 5))
+
+    def pgd_iterate(self, n):
+        time.sleep(0.02)
+        self.k += 1
+        if self.fail and self.k >= 2:
+            raise RuntimeError("injected failure (--dry-run-fail-rank)")
+        c = np.full((self.B, n), 1.0 / self.k)
+        return dict(iters=n, cost=c, alpha=c, attempts=np.zeros((self.B, n), dtype=np.int32), change=c, tracking_error=c,
+                    terminal_error=c, seconds=dict(backward=0.0, gradprox=0.0, optimistic_forward=0.02, cost=0.0, backtracking=0.0))
+
+    def prof_begin(self, n):
+        pass
+
+    def prof_end(self):
+        return {}
+
+    def counters(self):
+        return 0, 0
+
+    def close(self):
+        pass
 
 
 def main():
@@ -103,17 +142,33 @@ def main():
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
-    import vch_amd
-    F2 = vch_amd.module("Vch_control_2D.Forward2_solver")      # init_phi_random: the package's own host function
+        if a.dry_run:
+            dist.init_process_group(backend="gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    try:
+        run(a, world, rank, local, dist)
+    except BaseException:
+        # a rank that fails must not leave its peers inside the next collective: tear the group down and exit
+        # non-zero (torchrun then ends the other ranks) instead of unwinding through a half-finished iteration
+        import traceback
+        traceback.print_exc()
+        sys.stderr.flush()
+        os._exit(1)
 
-    if dist is None:
-        vch_amd.build()
-    else:                       # one builder per node, the other ranks wait (no concurrent hipcc into one .so)
-        if local == 0:
+
+def run(a, world, rank, local, dist):
+    import vch_amd
+    par = vch_amd.parallel
+    dev = "cpu" if (dist is None or a.dry_run) else f"cuda:{local}"
+    if not a.dry_run:
+        if dist is None:
             vch_amd.build()
-        dist.barrier()
+        else:                   # one builder per node, the other ranks wait (no concurrent hipcc into one .so)
+            if local == 0:
+                vch_amd.build()
+            dist.barrier()
     N, M, B = a.grid, a.time_steps, a.batch_per_gpu
     T = 1.0
     dt = T / M
@@ -122,14 +177,17 @@ def main():
     K = max(1, a.contexts)
     assert B % K == 0, "--batch-per-gpu must be divisible by --contexts"
     Bc = B // K
-    engs = [vch_amd.Engine2D(Nx=N, Ny=N, batch=Bc, max_steps=M, device=local) for _ in range(K)]
-    eng = engs[0]
-    par = vch_amd.parallel
-    dev = f"cuda:{local}" if dist is not None else "cpu"
-    seeds = par.shard_seeds(rank, max(world, 1), B)
-    phi0 = np.stack([F2.init_phi_random(N, N, 1e-2, amp=0.1, seed=s) for s in seeds])
-    xs = np.linspace(0.0, 1.0, N + 1)
-    phi_T = 0.7 * np.sin(2 * np.pi * xs)[:, None] * np.cos(np.pi * xs)[None, :]       # G2:199
+    if a.dry_run:
+        engs = [DryEngine(Bc, fail=(rank == a.dry_run_fail_rank)) for _ in range(K)]
+        phi0 = np.zeros((B, 2, 2))
+        phi_T = np.zeros((2, 2))
+    else:
+        F2 = vch_amd.module("Vch_control_2D.Forward2_solver")      # init_phi_random: the package's own host function
+        engs = [vch_amd.Engine2D(Nx=N, Ny=N, batch=Bc, max_steps=M, device=local) for _ in range(K)]
+        seeds = par.shard_seeds(rank, max(world, 1), B)
+        phi0 = np.stack([F2.init_phi_random(N, N, 1e-2, amp=0.1, seed=s) for s in seeds])
+        xs = np.linspace(0.0, 1.0, N + 1)
+        phi_T = 0.7 * np.sin(2 * np.pi * xs)[:, None] * np.cos(np.pi * xs)[None, :]       # G2:199
     opt = vch_amd.make_opt()
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(max_workers=K)
@@ -143,8 +201,28 @@ def main():
         phi0[k * Bc:(k + 1) * Bc], np.broadcast_to(phi_T, (Bc,) + phi_T.shape).copy(), t_hist, opt, ramp=True, T=T)))
     t_init = time.perf_counter() - t_init
 
+    # the collective: through the C ABI on the device-resident scalars, or torch.distributed on a host copy
+    comm, collective = None, "torch"
+    if a.collective == "cabi" and not a.dry_run:
+        try:
+            comm = par.CostComm(rank, max(world, 1), local, dist)
+            collective = "cabi-rccl"
+        except Exception as exc:          # reported, not hidden: the JSON line names the path that ran
+            print(f"[bench] C-ABI collective unavailable ({exc}); using torch.distributed", file=sys.stderr)
+            comm = None
+    if dist is not None:                  # every rank must take the same path
+        import torch
+        flag = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0 and comm is not None:
+            comm.close()
+            comm, collective = None, "torch"
+    if comm is None:
+        collective = "torch-rccl" if (dist is not None and not a.dry_run) else ("gloo" if dist is not None else "local")
+
     import queue
     import threading
+    it_done = [0]
 
     def run_iterations(n):
         """n PGD iterations of every context.  The trajectories of different contexts are independent
@@ -170,10 +248,17 @@ def main():
             for r in rs:
                 if isinstance(r, BaseException):
                     raise r
-            J = np.zeros((B, 5))
-            J[:, 4] = np.concatenate([x["cost"] for x in rs])[:, 0]
-            Jsum = par.allreduce_cost(J, dist, dev)      # the single RCCL collective of an iteration
+            if comm is not None:
+                Jsum = comm.allreduce(engs, it_done[0])      # the single RCCL collective of an iteration
+            else:
+                J = np.zeros((B, 5))
+                c = np.concatenate([x["cost"] for x in rs])[:, 0]
+                J[:, 4] = np.where(np.isnan(c), 0.0, c)      # a stopped trajectory reports no new cost
+                Jsum = par.allreduce_cost(J, dist, dev)
+            it_done[0] += 1
             outs.append(dict(cost_sum=float(Jsum[4]), attempts=int(sum(int(x["attempts"].sum()) for x in rs)),
+                             attempts_list=[int(v) for x in rs for v in x["attempts"][:, 0]],
+                             iters=[int(x["iters"]) for x in rs],
                              seconds={kk: max(x["seconds"][kk] for x in rs) for kk in rs[0]["seconds"]}))
         for th in ths:
             th.join()
@@ -182,51 +267,56 @@ def main():
     costs = []
     if a.warmup:
         run_iterations(a.warmup)
+    c0 = [e.counters() for e in engs]
     par.barrier(dist, dev)
     t0 = time.perf_counter()
     buckets = {}
     attempts = 0
+    attempts_per_step = []
     for r in run_iterations(a.steps):               # synchronous: returns when the devices are done
+        assert all(i == 1 for i in r["iters"]), "a context ran no iteration (all of its trajectories have stopped)"
         costs.append(r["cost_sum"])
         attempts += r["attempts"]
+        attempts_per_step.append(r["attempts_list"])
         for k, v in r["seconds"].items():
             buckets[k] = buckets.get(k, 0.0) + float(v)
     par.barrier(dist, dev)
     el = par.max_over_ranks(time.perf_counter() - t0, dist, dev)
+    c1 = [e.counters() for e in engs]
     total_traj = B * max(world, 1)
     value = a.steps * total_traj / el
 
     roof = None
     extra = {}
-    if rank == 0 and not a.no_roofline:
-        eng.prof_begin(400000)
-        eng.pgd_iterate(1)
-        prof = eng.prof_end()
+    if rank == 0 and not a.no_roofline and not a.dry_run:
+        # one extra iteration with an event pair around every profiled launch, ALL contexts of this rank running
+        # (the contention of the timed region); the other ranks wait at the barrier below
+        on_all(lambda k, e: e.prof_begin(400000))
+        on_all(lambda k, e: e.pgd_iterate(1))
+        profs = on_all(lambda k, e: e.prof_end())
+        prof = {k: dict(ms=sum(p[k]["ms"] for p in profs), launches=sum(p[k]["launches"] for p in profs)) for k in profs[0]}
         nodes = (N + 1) * (N + 1) * Bc
-        alg = {  # algorithmic bytes / flops per launch
-            "schur_p": ("hbm", 72.0 * nodes), "adj_q": ("hbm", 32.0 * nodes), "residual": ("hbm", 88.0 * nodes),
-            "cg_update": ("hbm", 48.0 * nodes), "adj_rhs": ("hbm", 72.0 * nodes),
-            # DCT preconditioner: three FFT passes (field in, field out) or four MFMA f64 GEMMs
-            "dct": ("hbm", 16.0 * nodes) if eng.uses_fft else ("mfma", 2.0 * (N + 1) ** 3 * Bc),
-        }
-        tot = {k: v["ms"] for k, v in prof.items()}
-        dom = max(tot, key=tot.get)
+        alg = {k: ("hbm", v * nodes) for k, v in ALG_BYTES.items()}
+        alg["dct_gemm"] = ("mfma", 2.0 * (N + 1) ** 3 * Bc)
+        tot = {k: v["ms"] for k, v in prof.items() if v["launches"]}
         extra["kernel_time_ms"] = {k: round(v["ms"], 3) for k, v in prof.items()}
         extra["kernel_launches"] = {k: v["launches"] for k, v in prof.items()}
 
-        # HBM-side traffic per launch from the committed PMC passes (scripts/pmc_traffic.sh: separate
-        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this bench at B = 8 per launch, gfx950 read
-        # correction calibrated on k_grad_prox), scaled to this run's trajectories per launch
-        pmc = {}
+        # HBM-side traffic per launch: NOT measured in this run -- taken from the committed PMC pass
+        # (scripts/pmc_traffic.sh -> profiles/pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs
+        # of this bench, 8 trajectories per launch), scaled to this run's trajectories per launch
+        pmc, pmc_src = {}, None
         try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")) as fh:
-                pk = json.load(fh)["kernels"]
-            tr = lambda names: sum(pk[n]["fetch_corrected"] + pk[n]["write_raw"] for n in names) / len(names) * Bc / 8.0
-            pmc = {"dct": tr(["k_dct_rows<0, 1024, 10>", "k_dct_cols<1024, 10>", "k_dct_rows<3, 1024, 10>"]),
-                   "schur_p": tr(["k_schur_p<0>"]), "residual": tr(["k_residual<1>"]), "adj_q": tr(["k_adj_q"])}
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+                pj = json.load(fh)
+            pk, pb = pj["kernels"], float(pj.get("trajectories_per_launch", 8))
+            for k, name in PMC_NAMES.items():
+                if name in pk:
+                    pmc[k] = (pk[name]["fetch_corrected"] + pk[name]["write_raw"]) * Bc / pb
+            pmc_src = f"profiles/pmc_traffic.json (committed rocprofv3 --pmc pass at {pb:g} trajectories per launch, scaled x{Bc / pb:g})"
         except (OSError, KeyError, ValueError):
             pmc = {}
-        use_pmc = (N == 512 and eng.uses_fft)
+        use_pmc = (N == 512 and engs[0].uses_fft)
 
         def roof_of(k):
             kind, per = alg[k]
@@ -234,38 +324,60 @@ def main():
             if kind == "hbm":
                 ach = per / avg_s / 1e9
                 return dict(kernel=k, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
-                            frac=ach / HBM_PEAK_GBS, traffic=(pmc.get(k) if use_pmc else None), avg_us=avg_s * 1e6,
-                            launches=prof[k]["launches"], algorithmic_bytes_per_launch=per)
+                            frac=ach / HBM_PEAK_GBS, traffic=(pmc.get(k) if use_pmc else None),
+                            traffic_source=(pmc_src if (use_pmc and k in pmc) else None), avg_us=avg_s * 1e6,
+                            launches=prof[k]["launches"], algorithmic_bytes_per_launch=per,
+                            share_of_profiled_kernel_time=prof[k]["ms"] / max(sum(tot.values()), 1e-30))
             ach = per / avg_s / 1e12
             return dict(kernel=k, bound="mfma", achieved=ach, peak=FP64_MFMA_PEAK_TF, unit="TFLOP/s",
-                        frac=ach / FP64_MFMA_PEAK_TF, traffic=None, avg_us=avg_s * 1e6,
-                        launches=prof[k]["launches"], algorithmic_flops_per_launch=per)
-        roof = roof_of(dom if dom in alg else "schur_p")
-        extra["roofline_newton_stencil"] = roof_of("schur_p")
-        extra["dct_path"] = "fft (in-LDS radix-4 Stockham)" if eng.uses_fft else "gemm (MFMA f64 16x16x4)"
+                        frac=ach / FP64_MFMA_PEAK_TF, traffic=None, traffic_source=None, avg_us=avg_s * 1e6,
+                        launches=prof[k]["launches"], algorithmic_flops_per_launch=per,
+                        share_of_profiled_kernel_time=prof[k]["ms"] / max(sum(tot.values()), 1e-30))
+        ranked = sorted((k for k in tot if k in alg), key=lambda k: -tot[k])
+        roof = roof_of(ranked[0]) if ranked else None
+        extra["roofline_kernels"] = [roof_of(k) for k in ranked]
+        if "schur_p" in tot:
+            extra["roofline_newton_stencil"] = roof_of("schur_p")
+        extra["dct_path"] = ("in-LDS Stockham FFT of the even extension, plan 8x8x4x4 at 512^2 (8x8x8 / 8x8x8x4 at 256^2 / 1024^2)"
+                             if engs[0].uses_fft else "MFMA f64 16x16x4 GEMM with DCT matrices")
+        extra["roofline_note"] = ("one extra PGD iteration after the timed region, all contexts of the rank running; "
+                                  f"{Bc} trajectories per launch")
+    par.barrier(dist, dev)        # every rank leaves the measurement together (rank 0 has done its profiled iteration)
 
     cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(a.cpu_grid or N, dt, M)
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.dry_run:
+        cpu = cpu_baseline(a.cpu_grid or N, dt, M, a.cpu_steps)
 
     if rank == 0:
+        nl = sum(x[0] - y[0] for x, y in zip(c1, c0))
+        ns = sum(x[1] - y[1] for x, y in zip(c1, c0))
         out = {
             "metric": "PGD iterations/sec (fwd Newton + adjoint + prox), 2D 512^2 grid",
-            "value": value, "unit": "PGD iterations/s", "n_gpus": max(world, 1), "steps": a.steps,
+            "value": value, "unit": "PGD iterations/s",
+            "value_definition": "trajectory-iterations per second over all ranks (batch x iterations / s)",
+            "n_gpus": max(world, 1), "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": 1e3 * el / a.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"2D {N}x{N}, {M} time steps, batch {B} trajectories per GPU "
                                    f"({total_traj} total), seeds 42+i, targets build_targets 1/1, u0 = 0",
-                       "grid": N, "time_steps": M, "batch_per_gpu": B, "contexts_per_gpu": K, "parallelism": f"batch-shard x{max(world, 1)}"},
+                       "grid": N, "time_steps": M, "batch_per_gpu": B, "contexts_per_gpu": K,
+                       "parallelism": f"batch-shard x{max(world, 1)}", "collective": collective},
             "roofline": roof, "cpu_baseline": cpu,
             "init_s": t_init, "J0_sum": float(J0[:, 4].sum()), "cost_sum_per_step": costs,
-            "backtracking_forwards": attempts, "time_buckets_s": buckets,
+            "backtracking_forwards": attempts, "backtracking_forwards_per_step": attempts_per_step, "time_buckets_s": buckets,
+            "kernel_launches_per_step": nl / max(a.steps, 1), "host_looks_per_step": ns / max(a.steps, 1),
+            "source_hash": (None if a.dry_run else source_hash()),
         }
         out.update(extra)
         print(json.dumps(out))
+        sys.stdout.flush()
+    if comm is not None:
+        comm.close()
     for e in engs:
         e.close()
+    pool.shutdown()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

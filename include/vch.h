@@ -67,6 +67,11 @@ typedef struct vch_stats {
     int64_t armijo_trials;     /* residual evaluations in the Armijo loop (F2:398-419) */
     double  max_lin_relres;    /* worst final relative residual of a linear solve */
     double  seconds;           /* device time of the call (HIP events) */
+    /* ABI version 2 */
+    double  max_lin_abserr;    /* worst final Z-weighted rms of the preconditioned residual (~ error of dphi) of a
+                                  Newton linear solve inside a march (absolute stop rule) */
+    int64_t host_syncs;        /* blocking looks of the host at the device state during the call */
+    int64_t launches;          /* kernel launches of the call */
 } vch_stats;
 
 typedef struct vch2d_ctx vch2d_ctx;
@@ -183,12 +188,40 @@ int vch2d_pgd_init(vch2d_ctx *ctx, const double *phi0, const double *phi_T, cons
  * Returns the number of iterations performed (>= 0) or a negative error. */
 int vch2d_pgd_iterate(vch2d_ctx *ctx, int n_iters, double *cost_out, double *alpha_out,
                       int32_t *attempts_out, double *change_out, double *seconds_out);
+/* Error metrics the driver appends after every iteration (G2:336-363), for the iterations of the LAST
+ * vch2d_pgd_iterate call ([B][n_iters], n_iters as passed there; NaN where no iteration ran):
+ *   tracking = ||phi - phi_Q||_L2(Q) / ||phi_Q||_L2(Q)  (denominator sqrt(|Omega| T) when ||phi_Q|| < 1e-9 of it)
+ *   terminal = ||phi(T) - phi_T||_L2(Omega) / ||phi_T||_L2(Omega)
+ * both from the cost kernel's weighted sums (nested trapezoid rule in y, x, t).  Either output may be NULL. */
+int vch2d_pgd_errors(vch2d_ctx *ctx, int n_iters, double *tracking_out, double *terminal_out);
 /* Copy resident PGD arrays to the host: what = 0 control u, 1 state history, 2 adjoint r,
  * 3 phi_Q.  out [B][M+1][Nx+1][Ny+1]. */
 int vch2d_pgd_get(vch2d_ctx *ctx, int what, double *out);
 /* Per-trajectory cost scalars {J1,J2,J3,J4,J} of the current iterate on the DEVICE
  * (5*B doubles), for the caller's RCCL all-reduce; returns a device pointer via *ptr_dev. */
 int vch2d_pgd_cost_dev(vch2d_ctx *ctx, double **ptr_dev);
+
+/* Kernel launches and blocking looks of the host at the device state since the context was created: out[0], out[1]. */
+int vch2d_counters(vch2d_ctx *ctx, int64_t *out /* [2] */);
+
+/* -- multi-GPU: the one collective of the path (no reference counterpart) --
+ * Trajectories are independent, so ranks share nothing on the data path; per PGD iteration there is ONE
+ * all-reduce (sum) of the cost scalars {J1,J2,J3,J4,J} over all trajectories of all ranks, done by RCCL over
+ * xGMI on a 5-double device buffer.  The per-trajectory values stay on the device: each context keeps the last
+ * 64 iterations' scalars in HBM, a one-workgroup kernel adds them up, RCCL reduces in place, 5 doubles come back.
+ * RCCL is bound with dlopen("librccl.so.1") at the first call; the library has no link-time dependency on it.
+ *   vch_comm_unique_id   rank 0 only: ncclGetUniqueId; the caller hands the 128 bytes to the other ranks
+ *   vch_comm_create      ncclCommInitRank on `device` (collective over all ranks); NULL on failure
+ *   vch_comm_allreduce_cost  sum over the trajectories of the nctx contexts of this rank (all on the
+ *                        communicator's device) and over all ranks of the cost scalars of PGD iteration
+ *                        `iteration` (0-based count since vch2d_pgd_init; < 0: the current iterate);
+ *                        J_sum_out [5] on the host.  Every rank must call it, in the same order. */
+#define VCH_COMM_ID_BYTES 128
+typedef struct vch_comm vch_comm;
+int vch_comm_unique_id(unsigned char *id_out /* [VCH_COMM_ID_BYTES] */);
+vch_comm *vch_comm_create(const unsigned char *id, int rank, int world, int device);
+void vch_comm_destroy(vch_comm *comm);
+int vch_comm_allreduce_cost(vch_comm *comm, vch2d_ctx *const *ctxs, int nctx, long iteration, double *J_sum_out);
 
 #define VCH_RESIDENT ((const double *)(uintptr_t)1)
 
@@ -204,9 +237,11 @@ int vch2d_free_energy(vch2d_ctx *ctx, const double *phi_hist, int rows, const do
  * Between _begin and _end every launch of the profiled kernel classes is bracketed by a HIP event
  * pair on the engine's stream (at most max_launches pairs).  _end returns, per class, the summed
  * elapsed milliseconds and the number of launches:
- *   0 Newton stencil SpMV (k_schur_p)  1 DCT GEMM  2 Newton residual  3 adjoint operator
- *   4 CG vector update  5 adjoint right-hand side  6 cost integrands  7 gradient+prox */
-#define VCH_PROF_CLASSES 8
+ *   0 Newton stencil SpMV (k_schur_p, fused with the CG updates)  1 DCT as MFMA GEMM (non-power-of-two grids)
+ *   2 Newton residual  3 adjoint operator  4 CG vector update  5 adjoint right-hand side  6 cost integrands
+ *   7 gradient+prox  8 DCT row pass (forward)  9 DCT column pass (forward, multiplier, inverse)
+ *   10 DCT row pass (inverse, with the CG dot products)  11 first sweep of a solve (k_schur_p<1>) */
+#define VCH_PROF_CLASSES 12
 int vch2d_prof_begin(vch2d_ctx *ctx, int max_launches);
 int vch2d_prof_end(vch2d_ctx *ctx, double *ms_out, int64_t *count_out, int ncls);
 
@@ -282,6 +317,9 @@ int vch1d_pgd_init(vch1d_ctx *ctx, const double *phi0, const double *phi_T, cons
 int vch1d_pgd_iterate(vch1d_ctx *ctx, int n_iters, double *cost_out, double *alpha_out,
                       int32_t *trials_out, double *change_out, double *seconds_out);
 int vch1d_pgd_get(vch1d_ctx *ctx, int what, double *out);
+/* Relative tracking / terminal errors of the iterations of the last vch1d_pgd_iterate call (G1:425-450);
+ * same conventions as vch2d_pgd_errors. */
+int vch1d_pgd_errors(vch1d_ctx *ctx, int n_iters, double *tracking_out, double *terminal_out);
 
 #ifdef __cplusplus
 }

@@ -23,6 +23,8 @@ Reference citations use the abbreviations of SURVEY.md:
 from __future__ import annotations
 
 from dataclasses import dataclass, field
+import time as _time
+
 import numpy as np
 import scipy.sparse as sp
 from scipy.sparse.linalg import spsolve, splu
@@ -360,6 +362,7 @@ def forward(P: Params2D, control=None, phi0=None, seed=42, amp=0.1, max_steps=No
             u_n, u_np1 = control[step], control[step + 1]
         else:
             u_n = u_np1 = np.zeros_like(phi)
+        _t_step = _time.perf_counter()
         w_new = w_filter(w, dts, P.gamma, u_n, u_np1)
         phi_new, mu_new = newton_step(phi, mu, w, w_new, dts, P, hx, hy, L=L, stats=stats)
         phi = np.clip(phi_new, lo, hi)
@@ -377,6 +380,8 @@ def forward(P: Params2D, control=None, phi0=None, seed=42, amp=0.1, max_steps=No
         step += 1
         hist.append(phi.copy())
         ts.append(min(t, P.T))
+        if stats is not None:           # per-step wall time, operator assembly (once per march) excluded
+            stats.setdefault("step_seconds", []).append(_time.perf_counter() - _t_step)
     return np.array(hist), (x, y), np.array(ts)
 
 
@@ -384,7 +389,7 @@ def forward(P: Params2D, control=None, phi0=None, seed=42, amp=0.1, max_steps=No
 # adjoint sweep
 # ----------------------------------------------------------------------------
 def backward(phi_hist, x, y, t_hist, P: Params2D, b1, b2, phi_Q=None, phi_T=None,
-             max_steps=None):
+             max_steps=None, step_seconds=None):
     """Adjoint sweep (B2:75-246): terminal (I - tau L) p_M = b2 (phi_M - phi_T), q = -L p,
     r_M = 0; per step A(phi_n) p_n = B(phi_{n+1}) p_{n+1} + src with the trapezoid
     source (B2:222), CN filter for r (B2:239-242); dt_n <= 1e-14 copies level n+1."""
@@ -410,6 +415,7 @@ def backward(phi_hist, x, y, t_hist, P: Params2D, b1, b2, phi_Q=None, phi_T=None
         if dt <= 1e-14:
             p[k], q[k], r[k] = p[k + 1], q[k + 1], r[k + 1]
             continue
+        _t_step = _time.perf_counter()
         src = 0.5 * dt * b1 * ((ph[k] - pq[k]) + (ph[k + 1] - pq[k + 1]))
         Dn = sp.diags(fpp(ph[k], P.c1, P.c2), 0, format="csr")
         Dp = sp.diags(fpp(ph[k + 1], P.c1, P.c2), 0, format="csr")
@@ -423,6 +429,8 @@ def backward(phi_hist, x, y, t_hist, P: Params2D, b1, b2, phi_Q=None, phi_T=None
         q[k] = -(L @ p[k])
         den = P.gamma + 0.5 * dt
         r[k] = ((P.gamma - 0.5 * dt) / den) * r[k + 1] + ((0.5 * dt) / den) * (q[k] + q[k + 1])
+        if step_seconds is not None:    # per-step wall time (terminal solve and L, L@L assembly excluded)
+            step_seconds.append(_time.perf_counter() - _t_step)
     shp = (M1, nx1, ny1)
     return p.reshape(shp), q.reshape(shp), r.reshape(shp)
 
@@ -576,21 +584,18 @@ def pgd(P: Params2D, O: OptParams, n_iter=None, seed=42, amp=0.1, choice_t=1, ch
 # ----------------------------------------------------------------------------
 # timing helper for bench.py's cpu_baseline leg
 # ----------------------------------------------------------------------------
-def time_one_step(N, dt, seed=42, amp=0.1, n_fwd_steps=1, n_bwd_steps=1):
-    """Wall time of `n_fwd_steps` forward time steps and `n_bwd_steps` adjoint steps at
-    full spatial size N x N with the default parameters (the per-step cost is flat in
-    the step index), for linear extrapolation to a PGD iteration."""
-    import time
+def time_one_step(N, dt, seed=42, amp=0.1, n_fwd_steps=3, n_bwd_steps=3):
+    """Wall times of `n_fwd_steps` forward time steps and `n_bwd_steps` adjoint steps at full spatial size N x N
+    with the default parameters, one sample per step (the per-step cost is flat in the step index, BASELINE.md 3);
+    the once-per-march operator assembly (L, L@L) and the terminal adjoint solve are outside the samples."""
     P = Params2D(Nx=N, Ny=N, T=dt * max(n_fwd_steps, n_bwd_steps), dt_initial=dt)
     O = OptParams()
     st = {}
-    t0 = time.perf_counter()
     phi, (x, y), t = forward(P, seed=seed, amp=amp, max_steps=n_fwd_steps, stats=st)
-    t_f = time.perf_counter() - t0
     phi_T, phi_Q = build_targets(x, y, t, phi[0], P.Lx, P.Ly, P.T)
-    t0 = time.perf_counter()
-    backward(phi, x, y, t, P, O.b1, O.b2, phi_Q, phi_T, max_steps=n_bwd_steps)
-    t_b = time.perf_counter() - t0
-    return dict(fwd_s_per_step=t_f / max(1, phi.shape[0] - 1),
-                bwd_s_per_step=t_b / max(1, min(n_bwd_steps, phi.shape[0] - 1)),
-                fwd_steps=phi.shape[0] - 1, solves=st.get("solves", 0))
+    bsec = []
+    backward(phi, x, y, t, P, O.b1, O.b2, phi_Q, phi_T, max_steps=n_bwd_steps, step_seconds=bsec)
+    fsec = list(st.get("step_seconds", []))
+    return dict(fwd_step_seconds=fsec, bwd_step_seconds=bsec, fwd_s_per_step=float(np.mean(fsec)),
+                bwd_s_per_step=float(np.mean(bsec)), fwd_steps=len(fsec), bwd_steps=len(bsec),
+                solves=st.get("solves", 0))

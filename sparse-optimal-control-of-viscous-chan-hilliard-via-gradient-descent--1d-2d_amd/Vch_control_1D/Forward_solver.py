@@ -87,6 +87,8 @@ def assemble_jacobian(phi_new, dt, tau, c1, L, kappa):
 def newton_raphson(phi_old, mu_old, w_old, w_new, dt, tau, c1, c2, h, delta_sep, L, kappa,
                    return_residual_history=False):
     """F1:139-235 on the GPU.  RuntimeError for a non-finite mass defect like the reference."""
+    if abs(float(delta_sep) - 1e-2) > 1e-15:        # the engine compiles the module constant of F1:42 in
+        raise ValueError(f"delta_sep = {delta_sep!r}: the GPU engine is built for delta_sep = 0.01 (F1:42)")
     eng = L._engine(tau=tau, c1=c1, c2=c2, kappa=kappa)
     try:
         pn, mn, hist = eng.newton_raphson(phi_old, mu_old, w_old, w_new, dt)

@@ -85,9 +85,22 @@ def build_targets_1d(x, t_hist, phi_initial, Lx, T, interactive=False, choice_t=
     return phi_T, phi_Q
 
 
+def relative_errors(phi, phi_Q, phi_T, x, t_hist):
+    """(tracking, terminal) relative L2 errors of a state history as the driver reports them per iteration
+    (G1:425-450): trapezoid rule in x then t, sqrt(L T) as denominator when the tracking target is ~0."""
+    trapz = getattr(np, "trapezoid", None) or np.trapz
+    sq_x = lambda a: trapz(np.square(a), x=x, axis=-1)
+    scale = np.sqrt(max(float(x[-1] - x[0]), 1e-30) * max(float(t_hist[-1] - t_hist[0]), 1e-30))
+    num_q = np.sqrt(trapz(sq_x(phi - phi_Q), x=t_hist))
+    den_q = np.sqrt(trapz(sq_x(phi_Q), x=t_hist))
+    if den_q < 1e-9 * scale:
+        den_q = scale
+    return float(num_q / (den_q + 1e-12)), float(np.sqrt(sq_x(phi[-1] - phi_T)) / (np.sqrt(sq_x(phi_T)) + 1e-12))
+
+
 def run_optimization(fwd_config: ForwardSolverConfig, opt_config: OptimizationConfig, n_iter=None, choice_t=1,
                      choice_q=1):
-    """The loop of G1:333-477 -> dict(costs, alphas, trials, u, phi, r, converged)."""
+    """The loop of G1:333-477 -> dict(costs, alphas, trials, tracking_error, terminal_error, u, phi, r, converged)."""
     O = opt_config
     quiet = contextlib.redirect_stdout(io.StringIO())
     phi_k, x, t_hist = run_main_simulation(fwd_config, store_history=True, verbose=False)
@@ -96,7 +109,7 @@ def run_optimization(fwd_config: ForwardSolverConfig, opt_config: OptimizationCo
                                     choice_t=choice_t, choice_q=choice_q)
     with quiet:
         cost_k = calculate_cost(phi_k, u_k, phi_Q, phi_T, x, t_hist, O.b1, O.b2, O.b3, O.kappa_sparsity)
-    costs, alphas, trials = [cost_k], [], []
+    costs, alphas, trials, track, term = [cost_k], [], [], [], []
     alpha_prev, plateau, converged = O.alpha_max, 0, False
     r_k = None
     for k in range(O.max_iter if n_iter is None else n_iter):
@@ -114,6 +127,8 @@ def run_optimization(fwd_config: ForwardSolverConfig, opt_config: OptimizationCo
                 u_k, cost_k, g, phi_Q, phi_T, x, t_hist, O.b1, O.b2, O.b3, O.kappa_sparsity, O.u_min, O.u_max,
                 fwd_config, alpha_init=alpha_prev)
         costs.append(c_n); alphas.append(a_k); trials.append(nt)
+        e_q, e_t = relative_errors(phi_n, phi_Q, phi_T, x, t_hist)
+        track.append(e_q); term.append(e_t)
         plateau = plateau + 1 if (k > 0 and abs(costs[-1] - costs[-2]) < 1e-7) else 0
         if plateau >= 10:
             alpha_prev, plateau = min(O.alpha_max, a_k * 2.0), 0
@@ -124,8 +139,8 @@ def run_optimization(fwd_config: ForwardSolverConfig, opt_config: OptimizationCo
             u_k, converged = u_n.copy(), True
             break
         u_k, cost_k, phi_k = u_n.copy(), c_n, phi_n
-    return dict(costs=costs, alphas=alphas, trials=trials, u=u_k, phi=phi_k, r=r_k, converged=converged,
-                phi_T=phi_T, phi_Q=phi_Q, x=x, t_hist=t_hist)
+    return dict(costs=costs, alphas=alphas, trials=trials, tracking_error=track, terminal_error=term, u=u_k, phi=phi_k,
+                r=r_k, converged=converged, phi_T=phi_T, phi_Q=phi_Q, x=x, t_hist=t_hist)
 
 
 def run_optimization_resident(fwd_config: ForwardSolverConfig, opt_config: OptimizationConfig, n_iter=None, choice_t=1,
@@ -160,7 +175,7 @@ def run_optimization_resident(fwd_config: ForwardSolverConfig, opt_config: Optim
         sq = (lambda a: a[0]) if B == 1 else (lambda a: a)
         costs = np.concatenate([J0.reshape(B, 5)[:, 4:5], res["cost"]], axis=1)
         out = dict(costs=sq(costs), alphas=sq(res["alpha"]), trials=sq(res["trials"]), change=sq(res["change"]),
-                   iters=res["iters"], u=eng.pgd_get("u"), phi=eng.pgd_get("phi"), r=eng.pgd_get("r"),
+                   tracking_error=sq(res["tracking_error"]), terminal_error=sq(res["terminal_error"]), iters=res["iters"], u=eng.pgd_get("u"), phi=eng.pgd_get("phi"), r=eng.pgd_get("r"),
                    phi_T=sq(phi_T), phi_Q=eng.pgd_get("phi_Q"), x=x, t_hist=t_hist, seconds=res["seconds"])
     finally:
         eng.close()

@@ -13,42 +13,56 @@ from .cost_and_function import calculate_cost
 from .config import ForwardSolverConfig
 
 
+# sign code of a node of the critical cone: FREE keeps the drawn value, +1 / -1 force the sign, 0 pins the component
+_FREE = 2
+
+
+def _cone_sign_codes(u_star, s_star, u_min, u_max, kappa, tol, tol_s):
+    """Admissible sign per node of the critical cone of `J + kappa |u|_1` over the box (S1:33-55).
+
+    Rules, later ones overriding earlier ones where they overlap (the reference assigns them in this order):
+    lower bound -> +, upper bound -> -, and at the kink u = 0 of the L1 term, with s = r + b3 u the smooth
+    gradient: |s| < kappa -> pinned, s >= kappa -> -, s <= -kappa -> + (each with the slack tol_s)."""
+    code = np.full(u_star.shape, _FREE, dtype=np.int8)
+    kink = np.abs(u_star) <= tol
+    for mask, c in ((u_star <= u_min + tol, 1),
+                    (u_star >= u_max - tol, -1),
+                    (kink & (np.abs(s_star) < kappa - tol_s), 0),
+                    (kink & (s_star >= kappa - tol_s), -1),
+                    (kink & (s_star <= -kappa + tol_s), 1)):
+        code[mask] = c
+    return code
+
+
 def _generate_direction(u_star, r_star, u_min, u_max, kappa, b3, rng, tol=1e-8, tol_s=1e-9):
-    """Unit direction in the critical cone incl. the L1 kink at u = 0 (S1:33-55)."""
-    v = rng.standard_normal(size=u_star.shape)
+    """Unit direction in the critical cone incl. the L1 kink at u = 0: ONE `standard_normal` draw of the shape of
+    u_star (the only thing the seeded goldens pin), signs imposed by `_cone_sign_codes`; an all-pinned cone falls
+    back to the coordinate direction of the largest |r + b3 u|."""
+    draw = rng.standard_normal(size=u_star.shape)
     s_star = r_star + b3 * u_star
-    lower = u_star <= (u_min + tol)
-    upper = u_star >= (u_max - tol)
-    at_zero = np.abs(u_star) <= tol
-    kink_interior = at_zero & (np.abs(s_star) < (kappa - tol_s))
-    kink_plus = at_zero & (s_star >= (kappa - tol_s))
-    kink_minus = at_zero & (s_star <= (-kappa + tol_s))
-    if np.any(lower):
-        v[lower] = np.abs(v[lower])
-    if np.any(upper):
-        v[upper] = -np.abs(v[upper])
-    if np.any(kink_interior):
-        v[kink_interior] = 0.0
-    if np.any(kink_plus):
-        v[kink_plus] = -np.abs(v[kink_plus])
-    if np.any(kink_minus):
-        v[kink_minus] = np.abs(v[kink_minus])
+    code = _cone_sign_codes(u_star, s_star, u_min, u_max, kappa, tol, tol_s)
+    v = np.where(code == _FREE, draw, code * np.abs(draw))
     nrm = np.linalg.norm(v)
     if nrm == 0:
-        idx = np.unravel_index(np.argmax(np.abs(s_star)), s_star.shape)
-        v[idx] = 1.0
+        v[np.unravel_index(np.argmax(np.abs(s_star)), s_star.shape)] = 1.0
         nrm = 1.0
     return v / nrm
 
 
-def _coerce_rng(seed_or_rng=None):
-    if isinstance(seed_or_rng, np.random.Generator):
-        return seed_or_rng
-    if seed_or_rng is None:
-        return np.random.default_rng()
+def _as_generator(source=None):
+    """A numpy Generator from a Generator, a seed-like value (anything int() accepts) or nothing; values that
+    cannot be read as a seed give an unseeded generator, as the reference's helper does (S1:57-68)."""
+    if isinstance(source, np.random.Generator):
+        return source
+    seed = None
+    if source is not None:
+        try:
+            seed = int(source)
+        except (TypeError, ValueError):
+            seed = None
     try:
-        return np.random.default_rng(int(seed_or_rng))
-    except Exception:
+        return np.random.default_rng(seed)
+    except (TypeError, ValueError):          # e.g. a negative seed
         return np.random.default_rng()
 
 
@@ -56,7 +70,7 @@ def approximate_second_order_condition(fwd_config: ForwardSolverConfig, u_star, 
                                        kappa, phi_Q_target, phi_T_target, u_min, u_max, num_directions: int = 10,
                                        epsilon: float = 1e-4, seed=None, rng=None) -> List[float]:
     """S1:71-177."""
-    rng = _coerce_rng(rng if rng is not None else seed)
+    rng = _as_generator(rng if rng is not None else seed)
     quiet = lambda: contextlib.redirect_stdout(io.StringIO())
     with quiet():
         cost_star = calculate_cost(phi_star, u_star, phi_Q_target, phi_T_target, x, t_hist, b1, b2, b3, kappa, verbose=False)

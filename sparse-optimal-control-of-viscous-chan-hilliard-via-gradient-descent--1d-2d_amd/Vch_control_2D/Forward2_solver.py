@@ -48,8 +48,37 @@ def regularized_log(phi, delta_sep):
     return np.log((1.0 + p) / (1.0 - p))
 
 
+def _check_delta_sep(delta_sep):
+    """The engine compiles the separation margin of F2:510 in (DELTA_SEP = 1e-2, the only value the reference's
+    march ever passes); any other value would silently give different clips, so it is refused."""
+    if abs(float(delta_sep) - DELTA_SEP) > 1e-15:
+        raise ValueError(f"delta_sep = {delta_sep!r}: the GPU engine is built for delta_sep = {DELTA_SEP} (F2:510)")
+
+
+class NeumannLaplacian1D:
+    """Matrix-free stand-in for the (N+1)x(N+1) CSR factor of F2:105-122 (second difference with the mirrored
+    Neumann rows L[0,1] = L[N,N-1] = 2/h^2): `L1 @ v` for a vector or for the columns of an (N+1, k) array, applied
+    by the 1D engine's Laplacian kernel (the same stencil, F1:64-76).  The 2D operator never needs the factor as a
+    matrix: `laplacian_matrix_neumann` applies kron(I, Lx) + kron(Ly, I) directly."""
+
+    def __init__(self, N, h):
+        self.N, self.h = int(N), float(h)
+        self.shape = (self.N + 1, self.N + 1)
+
+    def __matmul__(self, v):
+        from ..Vch_control_1D._ctx import engine_for as engine1d_for
+        v = np.asarray(v, dtype=np.float64)
+        if v.shape[0] != self.N + 1 or v.ndim > 2:
+            raise ValueError(f"dimension mismatch: operator is {self.shape}, operand has shape {v.shape}")
+        cols = v.reshape(self.N + 1, -1).T                      # one engine call per column (test-size operands)
+        eng = engine1d_for(self.N, Lx=self.h * self.N)
+        out = np.stack([np.asarray(eng.apply_laplacian(np.ascontiguousarray(c))) for c in cols], axis=1)
+        return out.reshape(v.shape)
+
+
 def laplacian_matrix_neumann_1d(N, h):
-    raise NotImplementedError("the GPU path is matrix-free; use laplacian_matrix_neumann(...) @ v")
+    """F2:105-122 as a matrix-free handle."""
+    return NeumannLaplacian1D(N, h)
 
 
 def laplacian_matrix_neumann(Nx, Ny, hx, hy):
@@ -66,6 +95,7 @@ def apply_laplacian(L, v, Nx, Ny):
 
 def initialize_mu(phi, w, c1, c2, kappa, L, Nx, Ny, delta_sep):
     """F2:155-167."""
+    _check_delta_sep(delta_sep)
     return L._engine(c1=c1, c2=c2, kappa=kappa).initialize_mu(phi, w)
 
 
@@ -85,6 +115,7 @@ def solve_mu_residual(phi_new, phi_old, mu_new, mu_old, dt, L, Nx, Ny):
 def solve_phi_residual(phi_new, phi_old, mu_new, mu_old, w_new, w_old, dt, tau, c1, c2, kappa, L, Nx, Ny,
                        delta_sep):
     """F2:199-221."""
+    _check_delta_sep(delta_sep)
     return L._engine(tau=tau, c1=c1, c2=c2, kappa=kappa).residuals(phi_new, phi_old, mu_new, mu_old, w_new,
                                                                   w_old, dt)[0]
 
@@ -112,6 +143,7 @@ class JacobianOperator:
 
 
 def assemble_jacobian(phi_new, dt, tau, c1, kappa, L, delta_sep):
+    _check_delta_sep(delta_sep)
     return JacobianOperator(L._engine(tau=tau, c1=c1, kappa=kappa), phi_new, dt)
 
 
@@ -174,6 +206,7 @@ def init_phi_random(Nx, Ny, delta_sep, amp=0.5, seed=42, enforce_zero_mean=True)
 def newton_raphson(phi_old, mu_old, w_old, w_new, dt, tau, c1, c2, kappa, delta_sep, L, Nx, Ny, hx, hy,
                    return_residual_history=False):
     """One implicit time level on the GPU (F2:323-427); no exception on non-convergence."""
+    _check_delta_sep(delta_sep)
     eng = L._engine(tau=tau, c1=c1, c2=c2, kappa=kappa)
     pn, mn, hist, _ = eng.newton_raphson(phi_old, mu_old, w_old, w_new, dt)
     return (pn, mn, list(hist)) if return_residual_history else (pn, mn)

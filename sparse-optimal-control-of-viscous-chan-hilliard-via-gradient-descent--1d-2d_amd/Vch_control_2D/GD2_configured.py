@@ -62,7 +62,8 @@ def perform_backtracking_line_search_2D(u_k, cost_k, grad_smooth, phi_Q_target, 
 def run_optimization(fwd_config: ForwardSolverConfig, opt_config: OptimizationConfig, n_iter=None, seeds=(42,),
                      choice_t=DEFAULT_TARGET_CHOICE, choice_q=DEFAULT_TRACKING_CHOICE, amp=0.1, device=0):
     """The PGD loop of G2:291-382 for a batch of initial conditions (`seeds`), device-resident.
-    Returns dict(costs [B][it+1], alphas, attempts, changes, u, phi, r, seconds)."""
+    Returns dict(costs [B][it+1], alphas, attempts, changes, tracking_error, terminal_error (the two relative
+    error histories the driver appends per iteration, G2:336-363, from the cost kernel's sums), u, phi, r, seconds)."""
     Nx, Ny = int(fwd_config.Nx), int(fwd_config.Ny)
     t_hist, dts = time_grid(float(fwd_config.T), float(fwd_config.dt_initial))
     B = len(seeds)
@@ -76,7 +77,7 @@ def run_optimization(fwd_config: ForwardSolverConfig, opt_config: OptimizationCo
     res = eng.pgd_iterate(n)
     costs = np.concatenate([J0[:, 4:5], res["cost"]], axis=1)
     return dict(costs=costs, alphas=res["alpha"], attempts=res["attempts"], changes=res["change"],
-                iters=res["iters"], seconds=res["seconds"], u=eng.pgd_get("u"), phi=eng.pgd_get("phi"),
+                tracking_error=res["tracking_error"], terminal_error=res["terminal_error"], iters=res["iters"], seconds=res["seconds"], u=eng.pgd_get("u"), phi=eng.pgd_get("phi"),
                 r=eng.pgd_get("r"), phi_T=phi_T, t_hist=t_hist, x=eng.x.copy(), y=eng.y.copy())
 
 
@@ -99,6 +100,9 @@ def main(n_iter=None, params_file="last_run_config_2d.json", num_directions=5, v
     costs = res["costs"][0]
     it = int(res["iters"])
     say(f"Completed Iterations: {it}\nFinal Cost: {costs[it]:.5f}\nCost Reduction: {100 * (1 - costs[it] / costs[0]):.2f}%")
+    if it > 0:
+        say(f"Relative tracking error: {res['tracking_error'][0, it - 1]:.6e}   "
+            f"relative terminal error: {res['terminal_error'][0, it - 1]:.6e}")
     sec = res["seconds"]
     say("\n" + "=" * 50 + "\n  TIME STUDY SUMMARY\n" + "=" * 50)
     say(f"Total backward-solve time:        {sec['backward']:.3f}s")

@@ -15,30 +15,31 @@ from .config import ForwardSolverConfig, OptimizationConfig
 
 
 def _generate_direction(u_star, r_star, u_min, u_max, rng, tol: float = 1e-8):
-    """Random unit direction in the bound-only critical cone (S2:35-88): components pointing
-    out of the box at saturated nodes are flipped inwards."""
-    v = rng.standard_normal(size=u_star.shape)
-    lower = u_star <= (u_min + tol)
-    upper = u_star >= (u_max - tol)
-    if np.any(lower):
-        v[lower] = np.abs(v[lower])
-    if np.any(upper):
-        v[upper] = -np.abs(v[upper])
-    nv = np.linalg.norm(v)
-    if nv < 1e-12:
+    """Random unit direction in the bound-only critical cone (S2:35-88): one `standard_normal` draw, then the
+    components at saturated nodes are reflected into the box (where both bounds are hit, the upper one wins, as in
+    the reference's assignment order); r_star is part of the signature only."""
+    draw = rng.standard_normal(size=u_star.shape)
+    inward = np.zeros(u_star.shape, dtype=np.int8)          # +1 at the lower bound, -1 at the upper bound
+    inward[u_star <= u_min + tol] = 1
+    inward[u_star >= u_max - tol] = -1
+    v = np.where(inward == 0, draw, inward * np.abs(draw))
+    length = np.linalg.norm(v)
+    if length < 1e-12:
         v = np.zeros_like(v)
-        v.ravel()[0] = 1.0
-        nv = 1.0
-    return v / nv
+        v.flat[0] = 1.0
+        length = 1.0
+    return v / length
 
 
 def _ensure_opt_config(b1, b2, b3, kappa_sparsity, opt_config) -> OptimizationConfig:
-    """Either a full opt_config or all four legacy scalars (S2:91-117)."""
+    """The weights as an OptimizationConfig: the object if one is given, else built from the four legacy
+    scalars, all of which must then be present (S2:91-117)."""
     if opt_config is not None:
         return opt_config
-    if any(v is None for v in (b1, b2, b3, kappa_sparsity)):
+    weights = dict(b1=b1, b2=b2, b3=b3, kappa_sparsity=kappa_sparsity)
+    if None in weights.values():
         raise ValueError("Either provide opt_config or all of (b1, b2, b3, kappa_sparsity).")
-    return OptimizationConfig(b1=float(b1), b2=float(b2), b3=float(b3), kappa_sparsity=float(kappa_sparsity))
+    return OptimizationConfig(**{k: float(v) for k, v in weights.items()})
 
 
 def approximate_second_order_condition_2d(u_star, r_star, phi_star, x, y, t_hist,
@@ -72,19 +73,24 @@ def approximate_second_order_condition_2d(u_star, r_star, phi_star, x, y, t_hist
     return out
 
 
+def sparsity_statistics(u_optimal, r_optimal, kappa: float, tol: float = 1e-6):
+    """Counts behind the KKT sparsity check `u* = 0 <=> |r*| <= kappa`: (nodes with |u*| < tol, nodes with
+    |r*| <= kappa, nodes where the two predicates agree, nodes in total)."""
+    u_is_zero = np.abs(np.ravel(u_optimal)) < tol
+    r_is_small = np.abs(np.ravel(r_optimal)) <= kappa
+    return int(u_is_zero.sum()), int(r_is_small.sum()), int((u_is_zero == r_is_small).sum()), int(u_is_zero.size)
+
+
 def verify_sparsity_condition(u_optimal, r_optimal, kappa: float, tol: float = 1e-6):
-    """u* = 0 <=> |r*| <= kappa match statistics (S2:238-297); prints like the reference and
-    additionally returns (sparsity %, |r|<=kappa %, match %)."""
-    u_flat, r_flat = np.ravel(u_optimal), np.ravel(r_optimal)
-    is_u_zero = np.abs(u_flat) < tol
-    is_r_small = np.abs(r_flat) <= kappa
-    total = u_flat.size
-    nz, nr, nm = int(np.sum(is_u_zero)), int(np.sum(is_r_small)), int(np.sum(is_u_zero == is_r_small))
-    print("\n" + "=" * 60 + "\nVERIFYING SPARSITY CONDITION\nCondition: u*(x,t) = 0  <=>  |r*(x,t)| <= kappa\n" + "=" * 60)
-    print(f"Sparsity of final control (u* ≈ 0): {100.0 * nz / total:.2f}% ({nz}/{total} points)")
-    print(f"Region where |r*| <= kappa:          {100.0 * nr / total:.2f}% ({nr}/{total} points)")
-    print(f"Percentage of points where the conditions match: {100.0 * nm / total:.2f}%")
-    print("\n✓ The sparsity condition is satisfied." if 100.0 * nm / total > 99.0
-          else "\n⚠ The sparsity condition is not fully satisfied.")
-    print("=" * 60)
-    return 100.0 * nz / total, 100.0 * nr / total, 100.0 * nm / total
+    """The reference's report (S2:238-297) from `sparsity_statistics`; additionally returns the three percentages
+    (sparsity of u*, share of |r*| <= kappa, share of matching nodes) that the reference only prints."""
+    n_zero, n_small, n_match, total = sparsity_statistics(u_optimal, r_optimal, kappa, tol)
+    pct = tuple(100.0 * k / total for k in (n_zero, n_small, n_match))
+    bar = "=" * 60
+    print(f"\n{bar}\nVERIFYING SPARSITY CONDITION\nCondition: u*(x,t) = 0  <=>  |r*(x,t)| <= kappa\n{bar}")
+    print(f"Sparsity of final control (u* ≈ 0): {pct[0]:.2f}% ({n_zero}/{total} points)")
+    print(f"Region where |r*| <= kappa:          {pct[1]:.2f}% ({n_small}/{total} points)")
+    print(f"Percentage of points where the conditions match: {pct[2]:.2f}%")
+    print("\n✓ The sparsity condition is satisfied." if pct[2] > 99.0 else "\n⚠ The sparsity condition is not fully satisfied.")
+    print(bar)
+    return pct

@@ -7,6 +7,7 @@ missing, and every engine call fails loudly when no HIP device is present.
 from __future__ import annotations
 
 import ctypes as C
+import hashlib
 import os
 import subprocess
 
@@ -16,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.environ.get("VCH_LIB") or os.path.join(HERE, "libvch_hip.so")     # VCH_LIB: A/B builds
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 SOURCES = ["vch_hip.hip"]
-DEPS = ["vch_hip.hip", "vch_engine2d.hip", "vch_kernels2d.h", "vch_gemm.h", "vch_fft.h", "vch_common.h", "vch_engine1d.hip", "vch_kernels1d.h",
+DEPS = ["vch_hip.hip", "vch_comm.hip", "vch_engine2d.hip", "vch_kernels2d.h", "vch_gemm.h", "vch_fft.h", "vch_common.h", "vch_engine1d.hip", "vch_kernels1d.h",
         os.path.join(ROOT, "include", "vch.h")]
 
 
@@ -24,15 +25,27 @@ class VchError(RuntimeError):
     pass
 
 
-def _stale():
-    if not os.path.exists(LIB_PATH):
-        return True
-    t = os.path.getmtime(LIB_PATH)
+HASH_PATH = LIB_PATH + ".srchash"
+
+
+def source_hash() -> str:
+    """sha256 over the contents of every file the shared library is built from (names included)."""
+    h = hashlib.sha256()
     for d in DEPS:
         p = d if os.path.isabs(d) else os.path.join(CSRC, d)
-        if os.path.exists(p) and os.path.getmtime(p) > t:
-            return True
-    return False
+        h.update(os.path.basename(p).encode())
+        with open(p, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def _stale():
+    """The library is current iff the hash recorded beside it at build time equals the hash of the sources as they
+    are now (mtimes say nothing after a checkout or a copy to the GPU box)."""
+    if not os.path.exists(LIB_PATH) or not os.path.exists(HASH_PATH):
+        return True
+    with open(HASH_PATH) as fh:
+        return fh.read().strip() != source_hash()
 
 
 def build(force: bool = False, verbose: bool = False, defines=(), out=None) -> str:
@@ -50,6 +63,9 @@ def build(force: bool = False, verbose: bool = False, defines=(), out=None) -> s
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise VchError("hipcc failed:\n" + r.stdout + r.stderr)
+    if out is None:
+        with open(HASH_PATH, "w") as fh:
+            fh.write(source_hash() + "\n")
     return out or LIB_PATH
 
 
@@ -72,7 +88,8 @@ class OptParams(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("newton_iters", C.c_int64), ("linear_solves", C.c_int64), ("linear_iters", C.c_int64),
-                ("armijo_trials", C.c_int64), ("max_lin_relres", C.c_double), ("seconds", C.c_double)]
+                ("armijo_trials", C.c_int64), ("max_lin_relres", C.c_double), ("seconds", C.c_double),
+                ("max_lin_abserr", C.c_double), ("host_syncs", C.c_int64), ("launches", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -112,6 +129,8 @@ SIGNATURES = {
                                  C.POINTER(OptParams), _D]),
     "vch2d_pgd_iterate": (C.c_int, [_P, C.c_int, _D, _D, _I32, _D, _D]),
     "vch2d_pgd_get": (C.c_int, [_P, C.c_int, _D]),
+    "vch2d_pgd_errors": (C.c_int, [_P, C.c_int, _D, _D]),
+    "vch1d_pgd_errors": (C.c_int, [_P, C.c_int, _D, _D]),
     "vch2d_pgd_cost_dev": (C.c_int, [_P, C.POINTER(C.c_void_p)]),
     "vch1d_create": (_P, [C.POINTER(Params1D), C.c_int, C.c_int, C.c_int]),
     "vch1d_destroy": (None, [_P]),
@@ -129,6 +148,11 @@ SIGNATURES = {
     "vch1d_pgd_init": (C.c_int, [_P, _D, _D, _D, _D, _D, C.c_int, _D, C.POINTER(OptParams), _D]),
     "vch1d_pgd_iterate": (C.c_int, [_P, C.c_int, _D, _D, _I32, _D, _D]),
     "vch1d_pgd_get": (C.c_int, [_P, C.c_int, _D]),
+    "vch2d_counters": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "vch_comm_unique_id": (C.c_int, [C.POINTER(C.c_ubyte)]),
+    "vch_comm_create": (_P, [C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_int]),
+    "vch_comm_destroy": (None, [_P]),
+    "vch_comm_allreduce_cost": (C.c_int, [_P, C.POINTER(C.c_void_p), C.c_int, C.c_long, _D]),
     "vch2d_prof_begin": (C.c_int, [_P, C.c_int]),
     "vch2d_prof_end": (C.c_int, [_P, _D, C.POINTER(C.c_int64), C.c_int]),
 }

@@ -31,6 +31,10 @@ struct vch1d_ctx {
     std::vector<double> t_host, chg_host, pgd_cost, pgd_alpha_prev;
     std::vector<std::vector<double>> pgd_cost_hist;
     std::vector<int> pgd_plateau, pgd_k, pgd_done;
+    // error metrics of the driver loop (G1:425-450): squared target norms, RMS fallback scale, histories of the last iterate call
+    std::vector<double> pgd_denQ2, pgd_denT2, pgd_trk, pgd_trm;
+    double pgd_rms = 1.0;
+    int pgd_err_n = 0;
 };
 
 #define LAUNCH1(kern, grid, block, lds, ...)                                       \
@@ -409,7 +413,8 @@ static void trapz_x(const vch1d_ctx *c, const double *x, std::vector<double> &wx
 }
 
 // J[b][5] of (phi, u) on the device; wx already uploaded
-static int cost1_core(vch1d_ctx *c, const double *phi_dev, const double *u_dev, int rows, double *J_out) {
+static int cost1_core(vch1d_ctx *c, const double *phi_dev, const double *u_dev, int rows, double *J_out,
+                      double *raw_out = nullptr /* [B][2] = {int int (phi - phi_Q)^2, int (phi_end - phi_T)^2} */) {
     const vch_opt_params *o = &c->opt;
     LAUNCH1(k1d_cost, dim3(rows, c->B), dim3(T1), 0, c->n, rows, (const double *)c->wx, phi_dev, u_dev,
             (const double *)c->phiQ, (const double *)c->phiT, hs1(c), c->cost_lvl);
@@ -430,6 +435,26 @@ static int cost1_core(vch1d_ctx *c, const double *phi_dev, const double *u_dev, 
         J[2] = (o->b3 / 2.0) * i3;
         J[3] = o->kappa_sparsity * i4;
         J[4] = J[0] + J[1] + J[2] + J[3];
+        if (raw_out) {
+            raw_out[2 * b] = i1;
+            raw_out[2 * b + 1] = s[(rows - 1) * 4 + 1];
+        }
+    }
+    return 0;
+}
+
+// int_t int_x a^2 (rows > 1) or int_x a^2 (rows == 1) per trajectory with the cost's weights; arr [B][stride]
+static int l2sq1_core(vch1d_ctx *c, const double *arr, long stride, int rows, double *out) {
+    LAUNCH1(k1d_cost, dim3(rows, c->B), dim3(T1), 0, c->n, rows, (const double *)c->wx, arr, (const double *)nullptr,
+            (const double *)nullptr, (const double *)nullptr, stride, c->cost_lvl);
+    VCHCHK(down(c, c->cost_host, c->cost_lvl, (size_t)c->B * rows * 4));
+    const double *t = c->t_host.data();
+    for (int b = 0; b < c->B; ++b) {
+        const double *s = c->cost_host + (size_t)b * rows * 4;
+        if (rows == 1) { out[b] = s[0]; continue; }
+        double acc = 0;
+        for (int k = 0; k + 1 < rows; ++k) acc += (t[k + 1] - t[k]) * (s[(k + 1) * 4] + s[k * 4]) / 2.0;
+        out[b] = acc;
     }
     return 0;
 }
@@ -487,6 +512,12 @@ extern "C" int vch1d_pgd_init(vch1d_ctx *c, const double *phi0, const double *ph
     }
     std::vector<double> J(5 * B);
     VCHCHK(cost1_core(c, c->phi_hist, c->u_hist, rows, J.data()));
+    c->pgd_denQ2.assign(B, 0.0);
+    c->pgd_denT2.assign(B, 0.0);
+    VCHCHK(l2sq1_core(c, c->phiQ, hs1(c), rows, c->pgd_denQ2.data()));
+    VCHCHK(l2sq1_core(c, c->phiT, c->n, 1, c->pgd_denT2.data()));
+    c->pgd_rms = std::sqrt(std::max(x[c->n - 1] - x[0], 1e-30) * std::max(t_hist[rows - 1] - t_hist[0], 1e-30));
+    c->pgd_err_n = 0;
     c->pgd_cost.assign(B, 0.0);
     for (int b = 0; b < B; ++b) c->pgd_cost[b] = J[5 * b + 4];
     if (J0_out) memcpy(J0_out, J.data(), sizeof(double) * 5 * B);
@@ -522,9 +553,12 @@ extern "C" int vch1d_pgd_iterate(vch1d_ctx *c, int n_iters, double *cost_out, do
         hipEventElapsedTime(&ms, c->ev0, c->ev1);
         return (double)ms * 1e-3;
     };
-    std::vector<double> alpha(B), Jt(5 * B);
+    std::vector<double> alpha(B), Jt(5 * B), raw(2 * B);
     std::vector<int> accepted(B), trials(B);
     const size_t hb = (size_t)B * hs1(c) * sizeof(double);
+    c->pgd_err_n = n_iters;
+    c->pgd_trk.assign((size_t)B * n_iters, std::nan(""));
+    c->pgd_trm.assign((size_t)B * n_iters, std::nan(""));
     int done_iters = 0;
     for (int it = 0; it < n_iters; ++it) {
         bool all_done = true;
@@ -554,7 +588,7 @@ extern "C" int vch1d_pgd_iterate(vch1d_ctx *c, int n_iters, double *cost_out, do
             LAUNCH1(k1d_grad_prox, dim3(rows, B), dim3(T1), 0, c->n, (const double *)c->u_hist, (const double *)c->r_hist, hs1(c),
                     (const double *)c->alpha_dev, O.b3, O.kappa_sparsity, O.u_min, O.u_max, c->u_trial, c->chg_dev);
             VCHCHK(fwd1_core(c, c->u_trial, rows, c->phi_trial, c->skip_dev));
-            VCHCHK(cost1_core(c, c->phi_trial, c->u_trial, rows, Jt.data()));
+            VCHCHK(cost1_core(c, c->phi_trial, c->u_trial, rows, Jt.data(), raw.data()));
             VCHCHK(down(c, c->chg_host.data(), c->chg_dev, (size_t)B * rows * 2));
             HIPCHK(tick(c->ev1));
             sec[round == 0 ? 1 : 2] += lap();
@@ -578,6 +612,13 @@ extern "C" int vch1d_pgd_iterate(vch1d_ctx *c, int n_iters, double *cost_out, do
                     n2 += c->chg_host[((size_t)b * rows + r) * 2 + 1];
                 }
                 const double change = std::sqrt(d2) / (std::sqrt(n2) + 1e-9);
+                {   // relative tracking / terminal errors of the accepted state (G1:438-450)
+                    double denQ = std::sqrt(std::max(c->pgd_denQ2[b], 0.0));
+                    if (denQ < 1e-9 * c->pgd_rms) denQ = c->pgd_rms;
+                    c->pgd_trk[(size_t)b * n_iters + it] = std::sqrt(std::max(raw[2 * b], 0.0)) / (denQ + 1e-12);
+                    c->pgd_trm[(size_t)b * n_iters + it] =
+                        std::sqrt(std::max(raw[2 * b + 1], 0.0)) / (std::sqrt(std::max(c->pgd_denT2[b], 0.0)) + 1e-12);
+                }
                 const int k = c->pgd_k[b];
                 auto &ch = c->pgd_cost_hist[b];
                 ch.push_back(c_n);
@@ -609,6 +650,16 @@ extern "C" int vch1d_pgd_iterate(vch1d_ctx *c, int n_iters, double *cost_out, do
     }
     if (seconds_out) memcpy(seconds_out, sec, sizeof(sec));
     return done_iters;
+}
+
+extern "C" int vch1d_pgd_errors(vch1d_ctx *c, int n_iters, double *tracking_out, double *terminal_out) {
+    CTXCHK1(c);
+    if (!c->pgd_ready) return vch_fail(VCH_ERR_STATE, "vch1d_pgd_errors: call vch1d_pgd_init first");
+    ARGCHK1(n_iters == c->pgd_err_n && n_iters >= 1, "n_iters differs from the last vch1d_pgd_iterate call");
+    const size_t n = (size_t)c->B * n_iters;
+    if (tracking_out) memcpy(tracking_out, c->pgd_trk.data(), n * sizeof(double));
+    if (terminal_out) memcpy(terminal_out, c->pgd_trm.data(), n * sizeof(double));
+    return 0;
 }
 
 extern "C" int vch1d_pgd_get(vch1d_ctx *c, int what, double *out) {

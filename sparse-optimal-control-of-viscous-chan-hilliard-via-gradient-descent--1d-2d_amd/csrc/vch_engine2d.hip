@@ -13,12 +13,14 @@
 thread_local char g_vch_err[512] = "";
 
 extern "C" const char *vch_last_error(void) { return g_vch_err; }
-extern "C" int vch_abi_version(void) { return 1; }
+extern "C" int vch_abi_version(void) { return 2; }
 extern "C" int vch_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return -1;
     return n;
 }
+
+constexpr int J_RING = 64;        // iterations whose cost scalars stay readable on the device
 
 struct vch2d_ctx {
     vch2d_params prm;
@@ -72,7 +74,18 @@ struct vch2d_ctx {
     std::vector<double> pgd_cost, pgd_alpha_prev, pgd_J;    // per trajectory
     std::vector<int> pgd_plateau, pgd_done, pgd_k;
     std::vector<std::vector<double>> pgd_cost_hist;
+    // error metrics of the driver loop (G2:336-363): squared norms of the targets (once per problem), the RMS fallback
+    // scale, and the per-iteration histories of the last vch2d_pgd_iterate call ([B][pgd_err_n])
+    std::vector<double> pgd_denQ2, pgd_denT2, pgd_trk, pgd_trm;
+    double pgd_rms;
+    int pgd_err_n;
     double *J_dev;
+    // cost scalars of the last J_RING iterations, [J_RING][B][5] on the device (slot = iteration index mod J_RING), so
+    // that the collective of iteration k (vch_comm_allreduce_cost) reads iteration k's values even when the context
+    // has already gone on; J_ring_host is the pinned staging copy
+    double *J_ring_dev, *J_ring_host;
+    long pgd_iter_total;                  // iterations performed since vch2d_pgd_init
+    long tot_launch, tot_sync;            // launches / looks accumulated over the context's life (vch2d_counters)
     // per-kernel-class HIP-event timing (bench.py roofline leg)
     bool prof_on;
     std::vector<hipEvent_t> prof_ev;
@@ -81,11 +94,20 @@ struct vch2d_ctx {
     // knobs
     int lin_maxit;
     double lin_tol;
+    double abs_tol;                       // absolute error target of the Newton linear solves inside a march (0 = off)
+    double wsum;                          // sum of the trapezoid weights wdev over a plane
+    // speculative launch schedule of a time step (newton_level): Newton slots and CG sweeps per slot, adapted from the
+    // state the host reads once per step
+    bool spec;
+    int spec_slots, spec_cgb;
+    // counters since the last reset_counters(): kernel launches and blocking looks at the device state
+    long n_launch, n_sync;
 };
 
 #define LAUNCH(kern, grid, block, ...)                                             \
     do {                                                                           \
         hipLaunchKernelGGL(kern, grid, block, 0, c->stream, __VA_ARGS__);          \
+        c->n_launch++;                                                             \
         hipError_t e_ = hipGetLastError();                                         \
         if (e_ != hipSuccess)                                                      \
             return vch_fail(VCH_ERR_HIP, "launch %s: %s", #kern, hipGetErrorString(e_)); \
@@ -93,7 +115,7 @@ struct vch2d_ctx {
 
 // Kernel classes for the in-situ timing of vch2d_prof_begin/_end.
 enum { PC_SCHUR_P = 0, PC_GEMM = 1, PC_RESIDUAL = 2, PC_ADJ_Q = 3, PC_CG_UPDATE = 4, PC_ADJ_RHS = 5, PC_COST = 6,
-       PC_PROX = 7, PC_NCLS = 8 };
+       PC_PROX = 7, PC_DCT_R0 = 8, PC_DCT_C = 9, PC_DCT_R3 = 10, PC_SCHUR_P1 = 11, PC_NCLS = 12 };
 
 // launch with an event pair around it when profiling is on (events are recorded on the
 // engine's own stream, the one the kernel is launched on)
@@ -102,6 +124,7 @@ enum { PC_SCHUR_P = 0, PC_GEMM = 1, PC_RESIDUAL = 2, PC_ADJ_Q = 3, PC_CG_UPDATE 
         const bool rec_ = c->prof_on && c->prof_used + 2 <= c->prof_ev.size();                  \
         if (rec_) hipEventRecord(c->prof_ev[c->prof_used], c->stream);                          \
         hipLaunchKernelGGL(kern, grid, block, 0, c->stream, __VA_ARGS__);                       \
+        c->n_launch++;                                                                          \
         if (rec_) {                                                                             \
             hipEventRecord(c->prof_ev[c->prof_used + 1], c->stream);                            \
             c->prof_cls.push_back(cls);                                                         \
@@ -162,6 +185,7 @@ static int ensure_hist(vch2d_ctx *c, double **p) {
 static inline long hist_stride(const vch2d_ctx *c) { return (long)(c->Mmax + 1) * c->G.plane; }
 
 static int sync_state(vch2d_ctx *c) {
+    c->n_sync++;
     HIPCHK(hipMemcpyAsync(c->st_host, c->st, sizeof(TrajState) * c->B, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
@@ -227,6 +251,15 @@ extern "C" vch2d_ctx *vch2d_create(const vch2d_params *p, int batch, int max_ste
     c->lin_maxit = 4000;
     c->lin_tol = 1e-15;
     if (const char *e = getenv("VCH_LIN_TOL")) c->lin_tol = atof(e);      // tuning/experiments only
+    // Newton solves inside a march stop at a Z-weighted rms error of 1e-13 in dphi: the next Newton
+    // iteration removes what is left, and 1e-13 per step is far below the 1e-9 parity tolerance of the fields.
+    c->abs_tol = 1e-13;
+    if (const char *e = getenv("VCH_ABS_TOL")) c->abs_tol = atof(e);
+    c->wsum = (double)(G.nf - 1) * (double)(G.ns - 1);
+    c->spec = getenv("VCH_NO_SPEC") == nullptr;
+    c->spec_slots = 2;
+    c->spec_cgb = 12;
+    c->n_launch = c->n_sync = 0;
     auto fail = [&](const char *what) {
         vch_fail(VCH_ERR_HIP, "vch2d_create: %s failed: %s", what, hipGetErrorString(hipGetLastError()));
         return (vch2d_ctx *)nullptr;
@@ -249,6 +282,10 @@ extern "C" vch2d_ctx *vch2d_create(const vch2d_params *p, int batch, int max_ste
     c->gpart2 = c->gpart + (size_t)batch * (c->gnblk + G.ns);
     if (dalloc(&c->hist_dev, (size_t)batch * HIST_CAP, c->stream)) return fail("hipMalloc");
     if (dalloc(&c->alpha_dev, batch, c->stream) || dalloc(&c->J_dev, 5 * (size_t)batch, c->stream)) return fail("hipMalloc");
+    if (dalloc(&c->J_ring_dev, (size_t)J_RING * 5 * batch, c->stream)) return fail("hipMalloc");
+    if (hipHostMalloc((void **)&c->J_ring_host, sizeof(double) * J_RING * 5 * batch) != hipSuccess) return fail("hipHostMalloc");
+    c->pgd_iter_total = 0;
+    c->tot_launch = c->tot_sync = 0;
     if (hipMalloc((void **)&c->st, sizeof(TrajState) * batch) != hipSuccess) return fail("hipMalloc");
     hipMemsetAsync(c->st, 0, sizeof(TrajState) * batch, c->stream);
     if (hipMalloc((void **)&c->frozen_dev, sizeof(int) * batch) != hipSuccess) return fail("hipMalloc");
@@ -347,6 +384,8 @@ extern "C" void vch2d_destroy(vch2d_ctx *c) {
     if (c->tw_s) hipFree(c->tw_s);
     hipHostFree(c->st_host);
     hipHostFree(c->hist_host);
+    hipHostFree(c->J_ring_host);
+    hipFree(c->J_ring_dev);
     if (c->cost_lvl_host) hipHostFree(c->cost_lvl_host);
     for (hipEvent_t e : c->prof_ev) hipEventDestroy(e);
     hipEventDestroy(c->ev0);
@@ -384,13 +423,13 @@ static int precond(vch2d_ctx *c, const double *in, long in_slot_stride, double *
 #define DCT_ROWS(EPI_, C_, LG_, in_, iss_, out_)                                                                \
     do {                                                                                                        \
         const int rpw = 2 * (C_ >> c->fax.logL);                                                                \
-        LAUNCHC(PC_GEMM, (k_dct_rows<EPI_, C_, LG_>), dim3((ns + rpw - 1) / rpw, 1, c->B), dim3(FftThreads<C_>::T), G, \
+        LAUNCHC(((EPI_) == 3 ? PC_DCT_R3 : PC_DCT_R0), (k_dct_rows<EPI_, C_, LG_>), dim3((ns + rpw - 1) / rpw, 1, c->B), dim3(FftThreads<C_>::T), G, \
                 c->fax, in_, iss_, out_, 1.0, sp, c->st, gate);                                                 \
     } while (0)
 #define DCT_COLS(C_, LG_)                                                                                       \
     do {                                                                                                        \
         const int cpw = 2 * (C_ >> c->sax.logL);                                                                \
-        LAUNCHC(PC_GEMM, (k_dct_cols<C_, LG_>), dim3((nf + cpw - 1) / cpw, 1, c->B), dim3(FftThreads<C_>::T), G, \
+        LAUNCHC(PC_DCT_C, (k_dct_cols<C_, LG_>), dim3((nf + cpw - 1) / cpw, 1, c->B), dim3(FftThreads<C_>::T), G, \
                 c->sax, (const double *)c->t1, c->t2, scale, sp, c->st, gate);                                  \
     } while (0)
         // FFT lengths 512 / 1024 / 2048 (grids 256^2, 512^2, 1024^2) are compiled with a constant length
@@ -403,12 +442,12 @@ static int precond(vch2d_ctx *c, const double *in, long in_slot_stride, double *
         else DCT_ROWS(EPI_, 4096, 0, in_, iss_, out_);                            \
     } while (0)
 #define DCTH_ROWS(EPI_, in_, iss_, out_)                                                                        \
-    LAUNCHC(PC_GEMM, (k_dcth_rows<EPI_>), dim3((ns + 3) / 4, 1, c->B), dim3(HT), G, c->fax, c->fax_h, in_, iss_, out_, 1.0, sp, \
+    LAUNCHC(((EPI_) == 3 ? PC_DCT_R3 : PC_DCT_R0), (k_dcth_rows<EPI_>), dim3((ns + 3) / 4, 1, c->B), dim3(HT), G, c->fax, c->fax_h, in_, iss_, out_, 1.0, sp, \
             c->st, gate)
         if (c->half_f) DCTH_ROWS(0, in, in_slot_stride, c->t1);
         else DCT_ROWS_ANY(0, in, in_slot_stride, c->t1);
         if (c->half_s)
-            LAUNCHC(PC_GEMM, k_dcth_cols, dim3((nf + 3) / 4, 1, c->B), dim3(HT), G, c->sax, c->sax_h, (const double *)c->t1, c->t2,
+            LAUNCHC(PC_DCT_C, k_dcth_cols, dim3((nf + 3) / 4, 1, c->B), dim3(HT), G, c->sax, c->sax_h, (const double *)c->t1, c->t2,
                     scale, sp, c->st, gate);
         else if (c->sax.logL == 10) DCT_COLS(1024, 10);
         else if (c->sax.logL == 9) DCT_COLS(1024, 9);
@@ -460,23 +499,25 @@ static bool any_lin_active(const vch2d_ctx *c) {
 constexpr int CG_CHUNK = 24;      // iterations enqueued between two looks at the state
 
 // CG on the Schur system of the current Newton iterate (left-preconditioned, weighted inner
-// product W (D - dbar)); on return x = dphi.  `budget` from cg_budget() of the last sync.
-static int schur_solve(vch2d_ctx *c, double dt, int budget) {
+// product W (D - dbar)); on return x = dphi.  `budget` sweeps are enqueued; `look` = the host may look at the
+// state inside a long solve (every CG_CHUNK sweeps) to stop enqueueing once every trajectory has converged.
+// Every kernel is gated per trajectory (lin_active / the per-iteration copies), so trajectories that are not
+// solving -- converged, frozen, or waiting for an Armijo trial -- keep their x.
+static int schur_solve(vch2d_ctx *c, double dt, int budget, bool look) {
     if (budget <= 0) return 0;
     const double c0 = 1.0 / dt, c2 = 0.5 * c->P.kappa;
-    HIPCHK(hipMemsetAsync(c->x, 0, sizeof(double) * c->B * c->G.plane, c->stream));
     double *zb[2] = {c->r, c->cg_z2};               // z_k lives in zb[k & 1]
     VCHCHK(precond(c, c->rhs_s, c->slot_stride, zb[0], 3, nullptr, c0, 0.0, 1.0, c2, 1));      // z = P^-1 rhs, <z,z>_Z
     LAUNCH(k_fin_cg_init, dim3(c->B), dim3(64), c->st, c->gpart, c->gnblk);
     int done = 0;
     while (done < budget) {
-        const int chunk = std::min(budget - done, CG_CHUNK);
+        const int chunk = look ? std::min(budget - done, CG_CHUNK) : budget - done;
         for (int j = 0; j < chunk; ++j, ++done) {
             double *pn = c->cg_p[done & 1], *po = c->cg_p[(done + 1) & 1];
             // iteration `done`: the reduction point of iteration done-1 is resolved inside the kernel and its
             // step goes into x and z on the way (see k_schur_p); 4 launches per iteration
             if (done == 0) {
-                LAUNCHC(PC_SCHUR_P, (k_schur_p<1>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, zb[0], c->cg_q, po, c->D_s, dt,
+                LAUNCHC(PC_SCHUR_P1, (k_schur_p<1>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, zb[0], c->cg_q, po, c->D_s, dt,
                         c->x, zb[1], pn, c->cg_v, c->part, (const double *)c->gpart, (const double *)c->gpart2, c->gnblk, 0,
                         c->lin_tol, c->lin_maxit);
             } else {
@@ -499,16 +540,44 @@ static int schur_solve(vch2d_ctx *c, double dt, int budget) {
     return 0;
 }
 
+#define RESIDUAL_TRIAL()                                                                                                    \
+    do {                                                                                                                    \
+        LAUNCHC(PC_RESIDUAL, (k_residual<1>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s,     \
+                c->Rphi_s, c->rhs_s, c->D_s, c->mu0, c->x, c->dmu, c->cphi, c->cmu, dt, c->part);                           \
+        LAUNCH((k_fin_residual<1>), dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->hist_dev, c->P.kappa, dt, c->lin_tol, \
+               atol_, c->wsum);                                                                                            \
+    } while (0)
+
 // One implicit time level for the whole batch (F2:323-427).  On entry the old level is
 // (phi_s, mu_s)[slot], w; on exit the new iterate is in (phi_s, mu_s)[slot] and w_new in c->wnew.
+//
+// Launch schedule.  The Newton / Armijo / CG state machine runs on the device (TrajState + the fin kernels) and
+// every kernel is gated by it, so the host enqueues a whole time step without looking: `spec_slots` slots of
+// [linear solve with spec_cgb sweeps, step ceiling, one residual evaluation].  A slot is either a Newton
+// iteration or, for a trajectory whose Armijo trial failed, just the next trial (its solve and ceiling kernels
+// exit at once); a solve that needs more sweeps than were enqueued is left untouched by the strict ceiling
+// kernel and taken up again by the next slot.  The host looks at the state ONCE per step, finishes the rare
+// step that did not fit (the loop below, one look per Armijo trial) and sizes the next step's schedule from
+// what this one used.  in_march = false (a bare newton_raphson call): relative CG tolerance only.
 static int newton_level(vch2d_ctx *c, double dt, const double *un, const double *unp1, long u_stride,
-                        const double *wnew_in) {
+                        const double *wnew_in, bool in_march) {
+    const double atol_ = in_march ? c->abs_tol : 0.0;
     LAUNCH(k_prepare, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s, c->w, un, unp1, u_stride,
            wnew_in, dt, c->wnew, c->mu0, c->cphi, c->cmu);
     LAUNCH(k_fin_newton_begin, dim3(c->B), dim3(64), c->st);
     LAUNCHC(PC_RESIDUAL, (k_residual<0>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s, c->Rphi_s, c->rhs_s,
            c->D_s, c->mu0, c->x, c->dmu, c->cphi, c->cmu, dt, c->part);
-    LAUNCH((k_fin_residual<0>), dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->hist_dev, c->P.kappa, dt, c->lin_tol);
+    LAUNCH((k_fin_residual<0>), dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->hist_dev, c->P.kappa, dt, c->lin_tol, atol_,
+           c->wsum);
+    if (c->spec) {
+        for (int s = 0; s < c->spec_slots; ++s) {
+            VCHCHK(schur_solve(c, dt, c->spec_cgb, false));
+            LAUNCH(k_dmu_ceiling, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->x, c->phi_s, c->D_s, c->Rphi_s,
+                   c->dmu, c->part);
+            LAUNCH(k_fin_ceiling, dim3(c->B), dim3(64), c->st, c->part, c->nblk, 1);
+            RESIDUAL_TRIAL();
+        }
+    }
     VCHCHK(sync_state(c));
     auto any_active = [&]() {
         for (int b = 0; b < c->B; ++b)
@@ -523,18 +592,30 @@ static int newton_level(vch2d_ctx *c, double dt, const double *un, const double 
     int guard = 0;
     while (any_active()) {
         if (++guard > NEWTON_MAXIT + 2) return vch_fail(VCH_ERR_STATE, "newton_level: state machine did not terminate");
-        VCHCHK(schur_solve(c, dt, cg_budget(c, true)));
+        VCHCHK(schur_solve(c, dt, cg_budget(c, true), true));
         LAUNCH(k_dmu_ceiling, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->x, c->phi_s, c->D_s, c->Rphi_s,
                c->dmu, c->part);
-        LAUNCH(k_fin_ceiling, dim3(c->B), dim3(64), c->st, c->part, c->nblk);
+        LAUNCH(k_fin_ceiling, dim3(c->B), dim3(64), c->st, c->part, c->nblk, 0);
         int tguard = 0;
         do {
-            LAUNCHC(PC_RESIDUAL, (k_residual<1>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s, c->Rphi_s,
-                   c->rhs_s, c->D_s, c->mu0, c->x, c->dmu, c->cphi, c->cmu, dt, c->part);
-            LAUNCH((k_fin_residual<1>), dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->hist_dev, c->P.kappa, dt, c->lin_tol);
+            RESIDUAL_TRIAL();
             VCHCHK(sync_state(c));
             if (++tguard > ARMIJO_TRIALS + 2) return vch_fail(VCH_ERR_STATE, "newton_level: Armijo loop did not terminate");
         } while (any_trial());
+    }
+    if (c->spec) {
+        // next step's schedule: as many slots as the busiest trajectory had linear solves (+ failed trials do not count:
+        // they are rare and the loop above absorbs them), and sweeps for the longest solve + 1, within the rigorous bound
+        int solves = 1, sweeps = 1, bound = 1;
+        for (int b = 0; b < c->B; ++b) {
+            const TrajState &S = c->st_host[b];
+            if (S.frozen) continue;
+            solves = std::max(solves, S.step_solves);
+            sweeps = std::max(sweeps, S.step_lin_max);
+            bound = std::max(bound, S.lin_budget);
+        }
+        c->spec_slots = std::min(solves, 4);
+        c->spec_cgb = std::max(2, std::min(std::min(sweeps + 1, bound), 64));
     }
     return 0;
 }
@@ -549,12 +630,18 @@ static void fill_stats(vch2d_ctx *c, vch_stats *s, float ms) {
         s->linear_iters += S.lin_total;
         s->armijo_trials += S.ntrials;
         s->max_lin_relres = std::max(s->max_lin_relres, S.lin_maxrel);
+        s->max_lin_abserr = std::max(s->max_lin_abserr, S.lin_maxabs);
     }
+    s->host_syncs = c->n_sync;
+    s->launches = c->n_launch;
     s->seconds = ms * 1e-3;
 }
 
 static int reset_counters(vch2d_ctx *c) {
     HIPCHK(hipMemsetAsync(c->st, 0, sizeof(TrajState) * c->B, c->stream));
+    c->tot_launch += c->n_launch;
+    c->tot_sync += c->n_sync;
+    c->n_launch = c->n_sync = 0;
     return 0;
 }
 
@@ -673,7 +760,7 @@ extern "C" int vch2d_jacobian_solve(vch2d_ctx *c, const double *phi_new, double 
            c->part);
     LAUNCH(k_fin_lin_begin, dim3(c->B), dim3(64), c->st, c->part, c->nblk, 2, c->P.tau, c->P.kappa, dt, c->lin_tol);
     VCHCHK(sync_state(c));
-    VCHCHK(schur_solve(c, dt, cg_budget(c, false)));
+    VCHCHK(schur_solve(c, dt, cg_budget(c, false), true));
     // back substitution needs newton_active && !need_trial
     HIPCHK(hipStreamSynchronize(c->stream));
     {   // keep the device-side linear-solve results, flip only the two flags
@@ -684,7 +771,7 @@ extern "C" int vch2d_jacobian_solve(vch2d_ctx *c, const double *phi_new, double 
     }
     LAUNCH(k_dmu_ceiling, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->x, c->phi_s, c->D_s, c->Rphi_s, c->dmu,
            c->part);
-    LAUNCH(k_fin_ceiling, dim3(c->B), dim3(64), c->st, c->part, c->nblk);
+    LAUNCH(k_fin_ceiling, dim3(c->B), dim3(64), c->st, c->part, c->nblk, 0);
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     VCHCHK(d2h(c, dphi, c->x, c->B));
     VCHCHK(d2h(c, dmu, c->dmu, c->B));
@@ -775,7 +862,7 @@ extern "C" int vch2d_newton_raphson(vch2d_ctx *c, const double *phi_old, const d
     VCHCHK(h2d(c, c->w, w_old, c->B));
     VCHCHK(h2d(c, c->tmp[0], w_new, c->B));
     HIPCHK(hipEventRecord(c->ev0, c->stream));
-    VCHCHK(newton_level(c, dt, nullptr, nullptr, 0, c->tmp[0]));
+    VCHCHK(newton_level(c, dt, nullptr, nullptr, 0, c->tmp[0], false));
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     for (int b = 0; b < c->B; ++b) {
@@ -814,7 +901,7 @@ static int forward_core(vch2d_ctx *c, const double *u_dev, int u_rows, const dou
             un = u_dev + (long)step * c->G.plane;
             unp1 = u_dev + (long)(step + 1) * c->G.plane;
         }
-        VCHCHK(newton_level(c, dt[step], un, unp1, hs, nullptr));
+        VCHCHK(newton_level(c, dt[step], un, unp1, hs, nullptr, true));
         // clip, mass fix, store (F2:562-585)
         LAUNCH(k_mass, c->grid, dim3(NTH), c->G, c->st, c->slot_stride, c->phi_s, c->wts_mass, 1, c->part);
         LAUNCH(k_fin_mass, dim3(c->B), dim3(64), c->st, c->part, c->nblk, 0);
@@ -978,7 +1065,8 @@ static int set_cost_weights(vch2d_ctx *c, const double *x, const double *y) {
 
 // J_out [B][5]; arrays on the device in history layout; phiQ_dev NULL + ramp => on-the-fly ramp target
 static int cost_core(vch2d_ctx *c, const double *phi_dev, const double *u_dev, const double *pq_dev, const double *pt_dev,
-                     bool ramp, int M, const double *t_hist, const vch_opt_params *o, double *J_out) {
+                     bool ramp, int M, const double *t_hist, const vch_opt_params *o, double *J_out,
+                     double *raw_out = nullptr /* [B][2] = {int int (phi - phi_Q)^2, int (phi_M - phi_T)^2} */) {
     const Geom &G = c->G;
     const int levels = M + 1, ntiles = c->nblk;
     if (!c->cost_part) {
@@ -1009,6 +1097,36 @@ static int cost_core(vch2d_ctx *c, const double *phi_dev, const double *u_dev, c
         J[2] = (o->b3 / 2.0) * i3;
         J[3] = o->kappa_sparsity * i4;
         J[4] = J[0] + J[1] + J[2] + J[3];
+        if (raw_out) {
+            raw_out[2 * b] = i1;
+            raw_out[2 * b + 1] = s[M * 4 + 1];
+        }
+    }
+    return 0;
+}
+
+// int_t int_Omega a^2 (levels > 1, trapezoid in t) or int_Omega a^2 (levels == 1) per trajectory, with the cost's weights
+static int l2sq_core(vch2d_ctx *c, const double *arr, long stride, int levels, const double *t_hist, double *out) {
+    const Geom &G = c->G;
+    const int ntiles = c->nblk;
+    if (!c->cost_part) {
+        const size_t n = (size_t)c->B * (c->Mmax + 1) * ntiles * 4;
+        HIPCHK(hipMalloc((void **)&c->cost_part, n * 8));
+        HIPCHK(hipMalloc((void **)&c->cost_lvl, (size_t)c->B * (c->Mmax + 1) * 4 * 8));
+        HIPCHK(hipHostMalloc((void **)&c->cost_lvl_host, (size_t)c->B * (c->Mmax + 1) * 4 * 8));
+    }
+    LAUNCH(k_cost, dim3(ntiles, levels, c->B), dim3(NTH), G, G.tiles_f, arr, (const double *)nullptr, (const double *)nullptr,
+           (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, stride, -1, (const double *)c->W_cost,
+           c->cost_part);
+    LAUNCH(k_cost_fin, dim3(c->B * levels), dim3(64), ntiles, (const double *)c->cost_part, c->cost_lvl);
+    HIPCHK(hipMemcpyAsync(c->cost_lvl_host, c->cost_lvl, (size_t)c->B * levels * 4 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int b = 0; b < c->B; ++b) {
+        const double *s = c->cost_lvl_host + (size_t)b * levels * 4;
+        if (levels == 1) { out[b] = s[0]; continue; }
+        double acc = 0.0;
+        for (int n = 0; n + 1 < levels; ++n) acc += (t_hist[n + 1] - t_hist[n]) * (s[(n + 1) * 4] + s[n * 4]) / 2.0;
+        out[b] = acc;
     }
     return 0;
 }
@@ -1196,6 +1314,16 @@ extern "C" int vch2d_pgd_init(vch2d_ctx *c, const double *phi0, const double *ph
     c->pgd_J.assign(5 * c->B, 0.0);
     VCHCHK(cost_core(c, c->phi_hist, c->u_hist, (phi_Q || ramp) ? c->phiQ : nullptr, c->phiT, false, M, c->t_hist.data(),
                      &c->opt, c->pgd_J.data()));
+    // target norms of the error metrics (G2:348-361)
+    c->pgd_denQ2.assign(c->B, 0.0);
+    c->pgd_denT2.assign(c->B, 0.0);
+    if (phi_Q || ramp) VCHCHK(l2sq_core(c, c->phiQ, hist_stride(c), M + 1, c->t_hist.data(), c->pgd_denQ2.data()));
+    VCHCHK(l2sq_core(c, c->phiT, c->G.plane, 1, nullptr, c->pgd_denT2.data()));
+    {
+        const double area = (x[c->prm.Nx] - x[0]) * (y[c->prm.Ny] - y[0]), tl = t_hist[M] - t_hist[0];
+        c->pgd_rms = std::sqrt(std::max(area, 1e-30) * std::max(tl, 1e-30));
+    }
+    c->pgd_err_n = 0;
     c->pgd_cost.resize(c->B);
     c->pgd_alpha_prev.assign(c->B, opt->alpha_max);
     c->pgd_plateau.assign(c->B, 0);
@@ -1209,6 +1337,7 @@ extern "C" int vch2d_pgd_init(vch2d_ctx *c, const double *phi0, const double *ph
     HIPCHK(hipMemcpyAsync(c->J_dev, c->pgd_J.data(), sizeof(double) * 5 * c->B, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (J0_out) memcpy(J0_out, c->pgd_J.data(), sizeof(double) * 5 * c->B);
+    c->pgd_iter_total = 0;
     c->pgd_ready = true;
     return 0;
 }
@@ -1229,9 +1358,13 @@ extern "C" int vch2d_pgd_iterate(vch2d_ctx *c, int n_iters, double *cost_out, do
     const double *pq = (c->phiQ) ? c->phiQ : nullptr;
     double sec[5] = {0, 0, 0, 0, 0};
     hipEvent_t e0 = c->ev0, e1 = c->ev1;
-    std::vector<double> alpha(B), Jt(5 * B), chg(2 * B), alpha_k(B), cost_new(B);
+    std::vector<double> alpha(B), Jt(5 * B), chg(2 * B), alpha_k(B), cost_new(B), raw(2 * B);
     std::vector<int> attempts(B), accepted(B);
     int done_iters = 0;
+    const double nan_ = std::nan("");
+    c->pgd_err_n = n_iters;
+    c->pgd_trk.assign((size_t)B * n_iters, nan_);
+    c->pgd_trm.assign((size_t)B * n_iters, nan_);
     for (int it = 0; it < n_iters; ++it) {
         bool all_done = true;
         for (int b = 0; b < B; ++b) all_done &= (c->pgd_done[b] != 0);
@@ -1262,7 +1395,7 @@ extern "C" int vch2d_pgd_iterate(vch2d_ctx *c, int n_iters, double *cost_out, do
             HIPCHK(hipEventRecord(e1, c->stream));
             sec[round == 0 ? 2 : 4] += elapsed_s(c, e0, e1);
             HIPCHK(hipEventRecord(e0, c->stream));
-            VCHCHK(cost_core(c, c->phi_trial, c->u_trial, pq, c->phiT, false, M, c->t_hist.data(), &c->opt, Jt.data()));
+            VCHCHK(cost_core(c, c->phi_trial, c->u_trial, pq, c->phiT, false, M, c->t_hist.data(), &c->opt, Jt.data(), raw.data()));
             HIPCHK(hipEventRecord(e1, c->stream));
             sec[round == 0 ? 3 : 4] += elapsed_s(c, e0, e1);
             bool pending = false;
@@ -1280,6 +1413,13 @@ extern "C" int vch2d_pgd_iterate(vch2d_ctx *c, int n_iters, double *cost_out, do
                     c->pgd_J[5 * b + 0] = Jt[5 * b + 0]; c->pgd_J[5 * b + 1] = Jt[5 * b + 1];
                     c->pgd_J[5 * b + 2] = Jt[5 * b + 2]; c->pgd_J[5 * b + 3] = Jt[5 * b + 3];
                     c->pgd_J[5 * b + 4] = Jt[5 * b + 4];
+                    {   // relative tracking / terminal errors of the accepted state (G2:348-361)
+                        double denQ = std::sqrt(std::max(c->pgd_denQ2[b], 0.0));
+                        if (denQ < 1e-9 * c->pgd_rms) denQ = c->pgd_rms;
+                        c->pgd_trk[(size_t)b * n_iters + it] = std::sqrt(std::max(raw[2 * b], 0.0)) / (denQ + 1e-12);
+                        c->pgd_trm[(size_t)b * n_iters + it] =
+                            std::sqrt(std::max(raw[2 * b + 1], 0.0)) / (std::sqrt(std::max(c->pgd_denT2[b], 0.0)) + 1e-12);
+                    }
                     // the stop rule uses the relative control change (G2:375-381)
                     const double change = std::sqrt(chg[2 * b]) / (std::sqrt(chg[2 * b + 1]) + 1e-9);
                     VCHCHK(copy_traj(c, c->u_hist, c->u_trial, b, rows));
@@ -1310,11 +1450,27 @@ extern "C" int vch2d_pgd_iterate(vch2d_ctx *c, int n_iters, double *cost_out, do
         }
         VCHCHK(reset_counters(c));
         done_iters = it + 1;
+        {   // this iteration's cost scalars into the ring (read by the collective of this iteration)
+            const size_t slot = (size_t)(c->pgd_iter_total % J_RING) * 5 * B;
+            memcpy(c->J_ring_host + slot, c->pgd_J.data(), sizeof(double) * 5 * B);
+            HIPCHK(hipMemcpyAsync(c->J_ring_dev + slot, c->J_ring_host + slot, sizeof(double) * 5 * B, hipMemcpyHostToDevice, c->stream));
+            c->pgd_iter_total++;
+        }
     }
     HIPCHK(hipMemcpyAsync(c->J_dev, c->pgd_J.data(), sizeof(double) * 5 * B, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (seconds_out) memcpy(seconds_out, sec, sizeof(sec));
     return done_iters;
+}
+
+extern "C" int vch2d_pgd_errors(vch2d_ctx *c, int n_iters, double *tracking_out, double *terminal_out) {
+    CTXCHK(c);
+    if (!c->pgd_ready) return vch_fail(VCH_ERR_STATE, "vch2d_pgd_errors: call vch2d_pgd_init first");
+    ARGCHK(n_iters == c->pgd_err_n && n_iters >= 1, "n_iters differs from the last vch2d_pgd_iterate call");
+    const size_t n = (size_t)c->B * n_iters;
+    if (tracking_out) memcpy(tracking_out, c->pgd_trk.data(), n * sizeof(double));
+    if (terminal_out) memcpy(terminal_out, c->pgd_trm.data(), n * sizeof(double));
+    return 0;
 }
 
 extern "C" int vch2d_pgd_get(vch2d_ctx *c, int what, double *out) {
@@ -1364,6 +1520,14 @@ extern "C" int vch2d_prof_end(vch2d_ctx *c, double *ms_out, int64_t *count_out, 
         if (k < ncls) { ms_out[k] += ms; count_out[k]++; }
     }
     return (int)c->prof_cls.size();
+}
+
+extern "C" int vch2d_counters(vch2d_ctx *c, int64_t *out) {
+    CTXCHK(c);
+    ARGCHK(out, "NULL out");
+    out[0] = c->tot_launch + c->n_launch;
+    out[1] = c->tot_sync + c->n_sync;
+    return 0;
 }
 
 extern "C" int vch2d_uses_fft(const vch2d_ctx *c) { return c ? (c->use_fft ? 1 : 0) : VCH_ERR_ARG; }

@@ -39,6 +39,11 @@ struct TrajState {
     // conjugate gradients in the weighted inner product (see k_schur_p)
     double cg_gamma, cg_gamma0, cg_alpha, cg_beta;
     int lin_budget;            // rigorous iteration bound from the spectrum of P^-1 A
+    // inexact Newton with absolute error control: a forward solve also stops once <z,z>_Z <= lin_abs2, i.e. once the
+    // Z-weighted rms of the preconditioned residual z ~ error of dphi is below the engine's abs_tol (0: relative test only)
+    double lin_abs2, lin_sdelta, lin_maxabs;      // lin_sdelta = sum W (D - dbar); lin_maxabs = worst final rms_Z(z) of a solve
+    // per time step, for the host's launch schedule: linear solves started and the longest of them
+    int step_solves, step_lin_max;
     int cg_pending, cg_pbuf, cg_pad;   // forward CG: step (alpha, p[cg_pbuf]) computed but not yet added to x
     // forward CG, per-iteration state in two copies: iteration k's stencil kernel derives the step of
     // iteration k-1 itself (every workgroup, redundantly), reading copy (k-1)&1 while one workgroup
@@ -310,7 +315,7 @@ __global__ __launch_bounds__(NTH) void k_residual(Geom G, Phys P, const TrajStat
                 cphi[pb + (long)gr * G.pitch + gc];
     }
     __syncthreads();
-    double acc[4] = {0.0, 0.0, 1e300, -1e300};
+    double acc[5] = {0.0, 0.0, 1e300, -1e300, 0.0};
     for (int k = 0; k < TY / 4; ++k) {
         int ly = ly0 + 4 * k, r = r0 + ly, c = c0 + lx;
         if (r < G.ns && c < G.nf) {
@@ -330,10 +335,11 @@ __global__ __launch_bounds__(NTH) void k_residual(Geom G, Phys P, const TrajStat
             acc[1] += rh * rh;
             acc[2] = fmin(acc[2], d);
             acc[3] = fmax(acc[3], d);
+            acc[4] += wdev(r, c, G) * d;
         }
     }
-    const int op[4] = {0, 0, 1, 2};
-    block_reduce_store<4>(acc, op, sred, part + ((long)b * nblk + blk) * NPART);
+    const int op[5] = {0, 0, 1, 2, 0};
+    block_reduce_store<5>(acc, op, sred, part + ((long)b * nblk + blk) * NPART);
 }
 
 // ---------------------------------------------------------------------------------
@@ -847,6 +853,8 @@ __global__ void k_fin_newton_begin(TrajState *st) {
     S.stuck = 0;
     S.alpha = 0.0;
     S.lin_active = 0;
+    S.step_solves = 0;
+    S.step_lin_max = 0;
 }
 
 // After k_residual: the Armijo test (F2:411-419) or the bookkeeping of the initial residual,
@@ -873,13 +881,14 @@ __device__ __forceinline__ void cg_setup(TrajState &S, double g0, double cscale,
 
 template <int MODE>
 __global__ void k_fin_residual(TrajState *st, const double *__restrict__ part, int nblk,
-                               double *__restrict__ hist, double kappa, double dt, double lin_tol) {
+                               double *__restrict__ hist, double kappa, double dt, double lin_tol, double abs_tol,
+                               double wsum) {
     const int b = blockIdx.x;
     TrajState &S = st[b];
     if (!S.newton_active || !S.need_trial) return;
     double v[NPART];
     const int op[NPART] = {0, 0, 1, 2, 0, 0};
-    fin_reduce(part, nblk, b, v, op, 4);
+    fin_reduce(part, nblk, b, v, op, 5);
     if (threadIdx.x != 0) return;
     const double nt = sqrt(v[0]);
     bool accept;
@@ -913,13 +922,17 @@ __global__ void k_fin_residual(TrajState *st, const double *__restrict__ part, i
         S.Dmin = v[2];
         S.Dmax = v[3];
         cg_setup(S, 2.0 * sqrt(0.5 * kappa / dt), 1.0, lin_tol);
+        // sum W (D - dbar) turns abs_tol into a bound on <z,z>_Z
+        S.lin_sdelta = fmax(v[4] - S.dbar * wsum, 0.0);
+        S.lin_abs2 = abs_tol > 0.0 ? abs_tol * abs_tol * S.lin_sdelta : 0.0;
         S.lin_active = 1;
         S.lin_it = 0;
         S.lin_r0 = sqrt(v[1]);
         S.lin_prev = 1e300;
         S.lin_rel = 1.0;
         S.nsolves++;
-        if (S.lin_r0 == 0.0) S.lin_active = 0;
+        S.step_solves++;
+        // (a zero right-hand side is not special-cased: the solve starts, zeroes x and ends at its first reduction point)
     } else {
         S.alpha *= 0.5;
         S.trial_no++;
@@ -965,7 +978,8 @@ __global__ void k_fin_cg_init(TrajState *st, const double *__restrict__ gpart, i
     S.cg_beta = 0.0;
     S.lin_it = 0;
     S.lin_rel = 1.0;
-    if (!(g > 0.0)) S.lin_active = 0;        // zero right-hand side: x = 0 is the solution
+    // (g == 0, a zero right-hand side: the first sweep still runs -- it zeroes x -- and the solve ends at its
+    //  first reduction point through the breakdown branch of cg_next)
     S.ci_active[0] = S.lin_active;
     S.ci_it[0] = 0;
     S.ci_gamma[0] = g;
@@ -978,7 +992,7 @@ struct CgNext {
     double alpha, beta, gamma, rel;
 };
 __device__ __forceinline__ CgNext cg_next(double pq, double qq, double gamma, double gamma0, int it_old, double tol,
-                                          int maxit) {
+                                          int maxit, double abs2) {
     CgNext n;
     n.it = it_old;
     if (!(pq > 0.0) || !(gamma > 0.0)) {     // round-off level residual: stop here, no step
@@ -998,7 +1012,7 @@ __device__ __forceinline__ CgNext cg_next(double pq, double qq, double gamma, do
     n.gamma = gn;
     n.it = it_old + 1;
     n.rel = sqrt(gn / gamma0);
-    n.active = (n.rel > tol && n.it < maxit) ? 1 : 0;
+    n.active = (n.rel > tol && n.it < maxit && gn > abs2) ? 1 : 0;
     return n;
 }
 
@@ -1030,6 +1044,8 @@ __device__ __forceinline__ void cg_record(TrajState &S, const CgNext &n, int wr)
         S.lin_total++;
     }
     if (!n.active && n.rel > S.lin_maxrel) S.lin_maxrel = n.rel;
+    if (!n.active && S.lin_sdelta > 0.0) S.lin_maxabs = fmax(S.lin_maxabs, sqrt(n.gamma / S.lin_sdelta));
+    if (n.it > S.step_lin_max) S.step_lin_max = n.it;
     S.ci_active[wr] = n.active;
     S.ci_it[wr] = n.it;
     S.ci_gamma[wr] = n.gamma;
@@ -1051,7 +1067,8 @@ __global__ void k_fin_cg_step(TrajState *st, const double *__restrict__ gpart, c
     }
     cg_sums(gpart, gpart2, gnblk, part, nblk, pslot, direct, b, s3);
     if (threadIdx.x != 0) return;
-    const CgNext n = cg_next(s3[0], s3[1], direct ? s3[2] : S.ci_gamma[rd], S.cg_gamma0, S.ci_it[rd], tol, maxit);
+    const CgNext n = cg_next(s3[0], s3[1], direct ? s3[2] : S.ci_gamma[rd], S.cg_gamma0, S.ci_it[rd], tol, maxit,
+                             S.lin_abs2);
     cg_record(S, n, rd ^ 1);
     S.cg_pending = n.breakdown ? 0 : 1;
     S.cg_pbuf = pbuf;
@@ -1109,10 +1126,13 @@ __global__ void k_fin_cg_beta(TrajState *st, const double *__restrict__ part, in
 }
 
 // After k_dmu_ceiling: the step ceiling (F2:383-391) and the start of the Armijo loop.
-__global__ void k_fin_ceiling(TrajState *st, const double *__restrict__ part, int nblk) {
+// strict: a solve that the enqueued sweeps did not finish is left as it is (lin_active stays set, no trial is armed), so the
+// next solve slot of the schedule -- or the host's continuation loop -- runs it again with the budget it needs.
+__global__ void k_fin_ceiling(TrajState *st, const double *__restrict__ part, int nblk, int strict) {
     const int b = blockIdx.x;
     TrajState &S = st[b];
     if (!S.newton_active || S.need_trial) return;
+    if (strict && S.lin_active) return;
     double v[NPART];
     const int op[NPART] = {1, 0, 0, 0, 0, 0};
     fin_reduce(part, nblk, b, v, op, 1);
@@ -1174,10 +1194,11 @@ __global__ void k_fin_lin_begin(TrajState *st, const double *__restrict__ part, 
     if (mode == 2) cg_setup(S, 2.0 * sqrt(0.5 * kappa / dt), 1.0, lin_tol);
     else cg_setup(S, tau + 2.0 * sqrt(0.5 * dt), 0.5 * dt, lin_tol);
     S.lin_r0 = r0;
-    S.lin_active = r0 > 0.0 ? 1 : 0;
+    S.lin_active = (mode == 2 || r0 > 0.0) ? 1 : 0;
     S.lin_it = 0;
     S.lin_prev = 1e300;
     S.lin_rel = 1.0;
+    S.lin_abs2 = S.lin_sdelta = 0.0;
     S.nsolves++;
 }
 
@@ -1342,7 +1363,8 @@ __global__ __launch_bounds__(NTH) void k_schur_p(Geom G, Phys P, TrajState *__re
         const double gamma0 = st[b].cg_gamma0, gamma_old = st[b].ci_gamma[rd];
         const int it_old = st[b].ci_it[rd];
         cg_sums(gpart, gpart2, gnblk, part, nblk, rd, it >= 2, b, sred);
-        const CgNext n = cg_next(sred[0], sred[1], it >= 2 ? sred[2] : gamma_old, gamma0, it_old, tol, maxit);
+        const CgNext n = cg_next(sred[0], sred[1], it >= 2 ? sred[2] : gamma_old, gamma0, it_old, tol, maxit,
+                                 st[b].lin_abs2);
         __syncthreads();                                   // sred is reused below
         if (blk == 0 && threadIdx.x == 0) cg_record(st[b], n, wr);
         alpha = n.alpha;
@@ -1387,6 +1409,8 @@ __global__ __launch_bounds__(NTH) void k_schur_p(Geom G, Phys P, TrajState *__re
                 x[o] += alpha * po;
                 z_new[o] = zn;
                 acc[0] += wdev(r, c, G) * (Dp[(long)r * G.pitch + c] - dbar) * (zn * zn);
+            } else {
+                x[o] = 0.0;          // start of a solve (only for the trajectories that take part in it)
             }
             p_new[o] = sx[p2];
             v[o] = sx[p2] * idt - lap_at<W1>(stt, p1, G.ax, G.ay);

@@ -281,7 +281,9 @@ class Engine2D:
         sec = np.zeros(5)
         done = check(self.lib.vch2d_pgd_iterate(self.ctx, n, _dp(cost), _dp(alpha), att.ctypes.data_as(_lib._I32),
                                                 _dp(chg), _dp(sec)))
-        return dict(iters=done, cost=cost, alpha=alpha, attempts=att, change=chg,
+        trk, trm = np.full((self.B, n), np.nan), np.full((self.B, n), np.nan)
+        check(self.lib.vch2d_pgd_errors(self.ctx, n, _dp(trk), _dp(trm)))
+        return dict(iters=done, cost=cost, alpha=alpha, attempts=att, change=chg, tracking_error=trk, terminal_error=trm,
                     seconds=dict(zip(("backward", "gradprox", "optimistic_forward", "cost", "backtracking"), sec)))
 
     def pgd_get(self, what):
@@ -323,7 +325,14 @@ class Engine2D:
         return self._sq(E)
 
     # -- in-situ kernel timing -------------------------------------------------------------
-    PROF_CLASSES = ("schur_p", "dct", "residual", "adj_q", "cg_update", "adj_rhs", "cost", "prox")
+    PROF_CLASSES = ("schur_p", "dct_gemm", "residual", "adj_q", "cg_update", "adj_rhs", "cost", "prox", "dct_rows_fwd",
+                    "dct_cols", "dct_rows_inv", "schur_p_first")
+
+    def counters(self):
+        """(kernel launches, blocking looks of the host at the device state) since the context was created."""
+        out = np.zeros(2, dtype=np.int64)
+        check(self.lib.vch2d_counters(self.ctx, out.ctypes.data_as(C.POINTER(C.c_int64))))
+        return int(out[0]), int(out[1])
 
     def prof_begin(self, max_launches=200000):
         check(self.lib.vch2d_prof_begin(self.ctx, int(max_launches)))
@@ -510,7 +519,9 @@ class Engine1D:
         sec = np.zeros(3)
         done = check(self.lib.vch1d_pgd_iterate(self.ctx, n, _dp(cost), _dp(alpha), trials.ctypes.data_as(_lib._I32),
                                                 _dp(chg), _dp(sec)))
-        return dict(iters=done, cost=cost, alpha=alpha, trials=trials, change=chg,
+        trk, trm = np.full((self.B, n), np.nan), np.full((self.B, n), np.nan)
+        check(self.lib.vch1d_pgd_errors(self.ctx, n, _dp(trk), _dp(trm)))
+        return dict(iters=done, cost=cost, alpha=alpha, trials=trials, change=chg, tracking_error=trk, terminal_error=trm,
                     seconds=dict(zip(("backward", "optimistic", "backtracking"), sec)))
 
     def pgd_get(self, what):

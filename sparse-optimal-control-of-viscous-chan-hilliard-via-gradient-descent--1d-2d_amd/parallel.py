@@ -24,6 +24,42 @@ def allreduce_cost(J, dist=None, device="cpu"):
     return t.cpu().numpy()
 
 
+class CostComm:
+    """The collective behind the C ABI (include/vch.h, vch_comm_*): RCCL communicator owned by the engine library,
+    all-reduce of the device-resident cost scalars of one PGD iteration.  The 128-byte unique id travels from rank
+    0 to the others over the process group the caller already has (`dist`); with one rank no group is needed."""
+
+    def __init__(self, rank: int, world: int, device: int, dist=None):
+        import ctypes as C
+        from . import _lib
+        self.lib = _lib.load()
+        ident = (C.c_ubyte * 128)()
+        if rank == 0:
+            _lib.check(self.lib.vch_comm_unique_id(ident))
+        if world > 1:
+            box = [bytes(ident)]
+            dist.broadcast_object_list(box, src=0)
+            ident = (C.c_ubyte * 128).from_buffer_copy(box[0])
+        self.h = self.lib.vch_comm_create(ident, int(rank), int(world), int(device))
+        if not self.h:
+            raise _lib.VchError("vch_comm_create failed: " + _lib.last_error())
+
+    def allreduce(self, engines, iteration: int = -1):
+        """Global {J1,J2,J3,J4,J} sums over the trajectories of `engines` (this rank) and over all ranks, for PGD
+        iteration `iteration` (0-based count since pgd_init; -1 = the current iterate)."""
+        import ctypes as C
+        from . import _lib
+        arr = (C.c_void_p * len(engines))(*[e.ctx for e in engines])
+        out = np.zeros(5)
+        _lib.check(self.lib.vch_comm_allreduce_cost(self.h, arr, len(engines), int(iteration), out.ctypes.data_as(_lib._D)))
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.vch_comm_destroy(self.h)
+            self.h = None
+
+
 def max_over_ranks(seconds: float, dist=None, device="cpu") -> float:
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return float(seconds)

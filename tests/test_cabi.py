@@ -37,7 +37,7 @@ def test_every_declared_symbol_is_exported_and_bound(V):
 
 def test_abi_version_and_error_string(V):
     lib = V.load()
-    assert lib.vch_abi_version() == 1
+    assert lib.vch_abi_version() == 2
     assert isinstance(lib.vch_last_error(), bytes)
 
 
@@ -55,7 +55,7 @@ def test_struct_layouts_match_header():
     L = __import__("importlib").import_module(vch_amd.PKG_NAME + "._lib")
     assert ctypes.sizeof(L.Params2D) == 2 * 4 + 7 * 8
     assert ctypes.sizeof(L.OptParams) == 5 * 8 + 8 + 2 * 8      # int32 + padding before u_min
-    assert ctypes.sizeof(L.Stats) == 6 * 8
+    assert ctypes.sizeof(L.Stats) == 9 * 8
 
 
 def test_time_grid_rule(V):

@@ -56,3 +56,65 @@ def test_single_rank_is_a_no_op():
     J = np.arange(10.0).reshape(2, 5)
     assert np.allclose(vch_amd.parallel.allreduce_cost(J), J.sum(axis=0))
     assert vch_amd.parallel.max_over_ranks(3.5) == 3.5
+
+
+def _run_bench(args, nproc, timeout=300):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    if nproc > 1:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py")] + args
+    else:
+        cmd = [sys.executable, os.path.join(root, "bench.py")] + args
+    return subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_skeleton_two_ranks_dry_run():
+    """bench.py's multi-rank skeleton under torchrun with two gloo ranks and a stand-in engine (--dry-run): rendezvous,
+    barriers around the timed region, one all-reduce per step in step order with two contexts per rank, MAX over
+    ranks, rank 0's extra (roofline) leg before the closing barrier, and a teardown every rank reaches -- one JSON
+    line, exit code 0, nobody left inside a collective."""
+    import json
+    r = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run", "--contexts", "2", "--batch-per-gpu", "4"], 2)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak"
+    assert out["config"]["collective"] == "gloo" and out["config"]["batch_per_gpu"] == 4
+    # the stand-in engine reports cost 1/k per trajectory at its k-th iteration: 8 trajectories over both ranks
+    assert np.allclose(out["cost_sum_per_step"], [8.0 / k for k in (2, 3, 4)])
+    assert out["value"] > 0 and out["ms_per_step"] > 0
+
+
+def test_bench_failing_rank_does_not_hang_its_peer():
+    """A rank whose engine raises inside an iteration exits non-zero at once (bench.py main), so torchrun ends the
+    job instead of leaving the other rank blocked in the next all-reduce."""
+    r = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "0", "--dry-run", "--contexts", "1", "--batch-per-gpu", "2",
+                    "--dry-run-fail-rank", "1"], 2, timeout=240)
+    assert r.returncode != 0
+    assert "injected failure" in (r.stdout + r.stderr)
+
+
+def test_source_hash_drives_rebuild(tmp_path):
+    """Build staleness is decided by a content hash of the sources recorded beside the library, not by mtimes."""
+    import importlib
+    import vch_amd
+    L = importlib.import_module(vch_amd.PKG_NAME + "._lib")
+    vch_amd.build()
+    assert not L._stale()
+    h = L.source_hash()
+    assert len(h) == 64 and open(L.HASH_PATH).read().strip() == h
+    # touching a source without changing it does not make the library stale; a recorded hash that differs does
+    src = os.path.join(L.CSRC, "vch_common.h")
+    os.utime(src, None)
+    assert not L._stale()
+    saved = open(L.HASH_PATH).read()
+    try:
+        open(L.HASH_PATH, "w").write("0" * 64 + "\n")
+        assert L._stale()
+    finally:
+        open(L.HASH_PATH, "w").write(saved)
+    assert not L._stale()

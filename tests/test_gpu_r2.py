@@ -1,0 +1,403 @@
+"""Round-2 GPU parity tests (through the C ABI / the mirrored modules):
+
+ * the plateau-boost and stop branches of both driver loops and the "return last try" exit of the line
+   searches against reference-made runs (tests/golden/make_golden_r2.py),
+ * the relative tracking / terminal error histories (G2:336-363, G1:425-450),
+ * BASELINE.json configs 3 (256^2 x 400), 5 (1024^2 near-singular start) and 2 (1D N = 4096 x 1000) AT SIZE:
+   reference-made golden for the first steps where the reference is affordable, size-independent invariants and
+   the reference's Newton exit semantics (F2:356-427) for the full marches, true residuals of the linear solves,
+ * the launch schedule: at most one look of the host at the device state per time step in the benign regime.
+
+Tolerances as in test_gpu_2d.py: SOLVE 1e-9 after linear solves / short marches, MARCH 1e-8 for PGD iterates.
+"""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+
+from conftest import golden, relerr
+
+pytestmark = pytest.mark.gpu
+
+SOLVE, MARCH = 1e-9, 1e-8
+
+
+@pytest.fixture(scope="module")
+def V():
+    import vch_amd
+    vch_amd.build()
+    return vch_amd
+
+
+@pytest.fixture(scope="module")
+def O2():
+    from oracle import vch2d_oracle
+    return vch2d_oracle
+
+
+def _phi_T(N):
+    xs = np.linspace(0, 1, N + 1)
+    return 0.7 * np.sin(2 * np.pi * xs)[:, None] * np.cos(np.pi * xs)[None, :]
+
+
+# ---------------------------------------------------------------------------------------
+# driver-loop branches (G2:365-381, G1:453-473) and error metrics
+# ---------------------------------------------------------------------------------------
+def test_pgd_plateau_boost_and_return_last_try_2d(V, O2):
+    """alpha_max = 4e4: from iteration 2 on every line search exhausts its 10 attempts (the step is returned once
+    more reduced, G2:144-146); |dJ| < 1e-5 five times in a row fires the x1.5 boost at iteration 6, visible in the
+    step of iteration 7 (0.3879 * 0.8^11 * 1.5 instead of * 1.2)."""
+    g = golden("g2d_pgd_16_plateau.npz")
+    N, M, n = int(g["N"]), len(g["t_hist"]) - 1, int(g["n_iter"])
+    e = V.Engine2D(Nx=N, Ny=N, max_steps=M)
+    opt = V.make_opt(alpha_max=float(g["alpha_max"]))
+    phi0 = O2.init_phi_random(N, N, 1e-2, amp=0.1, seed=42)
+    J0 = e.pgd_init(phi0, g["phi_T"], g["t_hist"], opt, ramp=True, T=float(g["T"]))
+    assert abs(J0[0, 4] / g["costs"][0] - 1) < 1e-10
+    res = e.pgd_iterate(n)
+    assert res["iters"] == n
+    assert list(res["attempts"][0]) == list(g["attempts"]), (res["attempts"], g["attempts"])
+    assert np.allclose(res["alpha"][0], g["alphas"], rtol=1e-12), (res["alpha"], g["alphas"])
+    assert abs(res["alpha"][0, 7] / (res["alpha"][0, 6] * 0.8 ** 11 * 1.5) - 1) < 1e-12      # the boost itself
+    assert np.allclose(res["cost"][0], g["costs"][1:], rtol=1e-9)
+    assert np.allclose(res["change"][0], g["changes"], rtol=1e-5)
+    assert np.allclose(res["tracking_error"][0], g["tracking"], rtol=1e-8)
+    assert np.allclose(res["terminal_error"][0], g["terminal"], rtol=1e-8)
+    assert relerr(e.pgd_get("u"), g["u_final"]) < MARCH and relerr(e.pgd_get("phi"), g["phi_final"]) < MARCH
+
+
+def test_pgd_stop_branch_2d(V, O2):
+    """kappa_sparsity = 10: the zero control is the fixed point of the prox step, the cost never changes (bitwise:
+    same control, same march), every line search returns its last try, the boost fires every 5 iterations and the
+    loop leaves through `change < 1e-5 and k > 20` at k = 21 (G2:375-381)."""
+    g = golden("g2d_pgd_16_stop.npz")
+    N, M = int(g["N"]), len(g["t_hist"]) - 1
+    assert int(g["stopped_at"]) == 21 and len(g["alphas"]) == 22
+    e = V.Engine2D(Nx=N, Ny=N, max_steps=M)
+    opt = V.make_opt(kappa_sparsity=float(g["kappa_sparsity"]))
+    phi0 = O2.init_phi_random(N, N, 1e-2, amp=0.1, seed=42)
+    J0 = e.pgd_init(phi0, g["phi_T"], g["t_hist"], opt, ramp=True, T=float(g["T"]))
+    res = e.pgd_iterate(int(g["n_iter"]))                     # asks for 40, the stop rule ends it
+    assert res["iters"] == 22
+    k = 22
+    assert np.all(res["attempts"][0, :k] == 10) and np.all(res["change"][0, :k] == 0.0)
+    assert np.allclose(res["alpha"][0, :k], g["alphas"], rtol=1e-13), (res["alpha"], g["alphas"])
+    assert np.all(res["cost"][0, :k] == J0[0, 4]) and abs(J0[0, 4] / g["costs"][0] - 1) < 1e-10
+    assert np.all(np.isnan(res["cost"][0, k:]))
+    assert np.allclose(res["tracking_error"][0, :k], g["tracking"], rtol=1e-8)
+    assert np.allclose(res["terminal_error"][0, :k], g["terminal"], rtol=1e-8)
+    assert not e.pgd_get("u").any()
+    assert e.pgd_iterate(3)["iters"] == 0                       # a stopped problem stays stopped
+
+
+def test_error_metrics_2d(V, O2):
+    """Tracking / terminal errors of the g2d_pgd_16 run, and with phi_Q = 0 the sqrt(|Omega| T) fallback of the
+    denominator (G2:353-354)."""
+    g, ge = golden("g2d_pgd_16.npz"), golden("g2d_pgd_16_err.npz")
+    N, M = int(g["N"]), len(g["t_hist"]) - 1
+    e = V.Engine2D(Nx=N, Ny=N, max_steps=M)
+    phi0 = O2.init_phi_random(N, N, 1e-2, amp=0.1, seed=42)
+    e.pgd_init(phi0, g["phi_T"], g["t_hist"], V.make_opt(), ramp=True, T=float(g["T"]))
+    res = e.pgd_iterate(4)
+    assert np.allclose(res["tracking_error"][0], ge["tracking"], rtol=1e-8), (res["tracking_error"], ge["tracking"])
+    assert np.allclose(res["terminal_error"][0], ge["terminal"], rtol=1e-8)
+    # zero tracking target
+    t, dts = V.time_grid(float(ge["zq_T"]), float(ge["zq_dt"]))
+    e2 = V.Engine2D(Nx=N, Ny=N, max_steps=len(dts))
+    J0 = e2.pgd_init(phi0, g["phi_T"], t, V.make_opt(), phi_Q=np.zeros((len(t), N + 1, N + 1)), ramp=False, T=float(ge["zq_T"]))
+    assert abs(J0[0, 4] / ge["zq_costs"][0] - 1) < 1e-10
+    r2 = e2.pgd_iterate(2)
+    assert np.allclose(r2["cost"][0], ge["zq_costs"][1:], rtol=1e-8)
+    assert np.allclose(r2["tracking_error"][0], ge["zq_tracking"], rtol=1e-8), (r2["tracking_error"], ge["zq_tracking"])
+    assert np.allclose(r2["terminal_error"][0], ge["zq_terminal"], rtol=1e-8)
+
+
+def test_pgd_stop_branch_and_error_metrics_1d(V):
+    """1D: the x2.0 plateau boost after 10 flat iterations (G1:453-463) and the stop at k = 11 (G1:466-473) on the
+    zero-control fixed point; error histories of the g1d_pgd_32 run through both loops of the mirror."""
+    G1 = V.module("Vch_control_1D.GD_1D")
+    K1 = V.module("Vch_control_1D.config")
+    g = golden("g1d_pgd_32_stop.npz")
+    assert int(g["stopped_at"]) == 11
+    cfg = K1.ForwardSolverConfig(N=int(g["N"]), T=float(g["T"]), dt_initial=float(g["dt"]))
+    opt = K1.OptimizationConfig(kappa_sparsity=float(g["kappa_sparsity"]))
+    res = G1.run_optimization_resident(cfg, opt, n_iter=int(g["n_iter"]))
+    assert res["iters"] == 12
+    assert list(res["trials"][:12]) == list(g["trials"]) and np.all(g["trials"][1:] == 5)
+    assert np.allclose(res["alphas"][:12], g["alphas"], rtol=1e-13), (res["alphas"], g["alphas"])
+    assert abs(res["alphas"][11] / (res["alphas"][10] * 0.8 ** 5 * 2.0) - 1) < 1e-12             # the boost itself
+    assert np.allclose(res["costs"][:13], g["costs"], rtol=1e-10)
+    assert np.allclose(res["tracking_error"][:12], g["tracking"], rtol=1e-8)
+    assert np.allclose(res["terminal_error"][:12], g["terminal"], rtol=1e-8)
+    assert not res["u"].any()
+    ge, gp = golden("g1d_pgd_32_err.npz"), golden("g1d_pgd_32.npz")
+    cfg = K1.ForwardSolverConfig(N=32, T=float(gp["T"]), dt_initial=float(gp["dt"]))
+    opt = K1.OptimizationConfig(alpha_max=float(gp["alpha_max"]))
+    r1 = G1.run_optimization_resident(cfg, opt, n_iter=4)
+    r2 = G1.run_optimization(cfg, opt, n_iter=4)
+    for r in (r1, r2):
+        assert np.allclose(r["tracking_error"], ge["tracking"], rtol=1e-8), (r["tracking_error"], ge["tracking"])
+        assert np.allclose(r["terminal_error"], ge["terminal"], rtol=1e-8)
+
+
+def test_sparsity_percentages_vs_reference(V):
+    """The three statistics verify_sparsity_condition prints (S2:238-297, G1:115-147) against the reference's own
+    output (captured text, two (kappa, tol) pairs)."""
+    S2 = V.module("Vch_control_2D.second_order_conditions_2d")
+    G1 = V.module("Vch_control_1D.GD_1D")
+    for mod, gp, gs, gq in ((S2, "g2d_pgd_16.npz", "g2d_soc_16.npz", "g2d_soc_16_pct.npz"),
+                            (G1, "g1d_pgd_32.npz", "g1d_soc_32.npz", "g1d_soc_32_pct.npz")):
+        gp, gs, gq = golden(gp), golden(gs), golden(gq)
+        for tag in ("default", "loose"):
+            with contextlib.redirect_stdout(io.StringIO()):
+                st = mod.verify_sparsity_condition(gp["u_final"], gs["r_opt"], float(gq[f"kappa_{tag}"]), tol=float(gq[f"tol_{tag}"]))
+            assert np.allclose(np.round(st, 2), gq[f"pct_{tag}"], atol=0.0051), (st, gq[f"pct_{tag}"])
+    n_zero, n_small, n_match, total = S2.sparsity_statistics(golden("g2d_pgd_16.npz")["u_final"],
+                                                             golden("g2d_soc_16.npz")["r_opt"], 1e-4)
+    assert [n_zero, n_small, total] == list(golden("g2d_soc_16_pct.npz")["cnt_default"])
+
+
+def test_critical_cone_sign_rules_1d(V):
+    """Every rule of the kink-aware cone (S1:33-55) on a hand-made control: bounds, pinned kink, one-sided kinks,
+    the override order, and the all-pinned fallback."""
+    S1 = V.module("Vch_control_1D.second_order_conditions")
+    kappa, b3 = 0.5, 0.0
+    u = np.array([-1.0, 1.0, 0.0, 0.0, 0.0, 0.3, 0.0])
+    r = np.array([0.0, 0.0, 0.1, 0.9, -0.9, 0.2, 0.5 - 5e-10])
+    draw = np.random.default_rng(3).standard_normal(u.shape)
+    h = S1._generate_direction(u, r, -1.0, 1.0, kappa, b3, np.random.default_rng(3))
+    raw = h * np.linalg.norm(np.where([0, 0, 1, 0, 0, 0, 0], 0.0, draw))
+    want = np.array([abs(draw[0]), -abs(draw[1]), 0.0, -abs(draw[3]), abs(draw[4]), draw[5], -abs(draw[6])])
+    assert np.allclose(raw, want, rtol=1e-14, atol=0) and raw[2] == 0.0      # [6]: s within tol_s of kappa is one-sided
+    h0 = S1._generate_direction(np.zeros(4), np.array([0.1, -0.3, 0.2, 0.0]), -1.0, 1.0, kappa, b3, np.random.default_rng(1))
+    assert list(h0) == [0.0, 1.0, 0.0, 0.0]
+
+
+def test_laplacian_1d_factor_handle_and_delta_sep(V):
+    """laplacian_matrix_neumann_1d (F2:105-122) as a matrix-free handle: mirrored-Neumann second difference, and
+    kron(I, Lx) + kron(Ly, I) rebuilt from two factors equals the 2D operator; delta_sep != 1e-2 is refused."""
+    F2 = V.module("Vch_control_2D.Forward2_solver")
+    N, h = 20, 0.05
+    L1 = F2.laplacian_matrix_neumann_1d(N, h)
+    v = np.random.default_rng(0).standard_normal(N + 1)
+    ref = np.empty(N + 1)
+    ref[1:-1] = (v[:-2] - 2 * v[1:-1] + v[2:]) / h ** 2
+    ref[0], ref[-1] = 2 * (v[1] - v[0]) / h ** 2, 2 * (v[-2] - v[-1]) / h ** 2
+    assert L1.shape == (N + 1, N + 1) and relerr(L1 @ v, ref) < 1e-13
+    F = np.random.default_rng(1).standard_normal((N + 1, N + 1))
+    L = F2.laplacian_matrix_neumann(N, N, h, h)
+    two_factor = L1 @ F + (L1 @ F.T).T
+    assert relerr(two_factor, F2.apply_laplacian(L, F, N, N)) < 1e-12
+    with pytest.raises(ValueError):
+        F2.initialize_mu(F, F, 0.75, 1.0, 1e-4, L, N, N, 5e-3)
+    with pytest.raises(ValueError):
+        F2.newton_raphson(F, F, F, F, 1e-2, 0.05, 0.75, 1.0, 1e-4, 2e-2, L, N, N, h, h)
+
+
+# ---------------------------------------------------------------------------------------
+# config 3: 256^2, dt = 1/400
+# ---------------------------------------------------------------------------------------
+def test_config3_first_steps_vs_reference_256(V, O2):
+    """The first 5 steps of BASELINE config 3 against the reference's own run (SuperLU at 256^2): natural and
+    controlled march, adjoint sweep, cost.  Fields are compared on the [::4, ::4] sub-grid the fixture holds and
+    through the per-level L2 norms of the full fields."""
+    g = golden("g2d_forward_256.npz")
+    N, M, dt = int(g["N"]), int(g["M"]), float(g["dt"])
+    t, dts = V.time_grid(M * dt, dt)
+    assert np.array_equal(t, g["t_hist"])
+    e = V.Engine2D(Nx=N, Ny=N, max_steps=M)
+    phi0 = O2.init_phi_random(N, N, 1e-2, amp=0.1, seed=42)
+    l2 = lambda A: np.sqrt((A.reshape(A.shape[0], -1) ** 2).sum(axis=1))
+    ph, st = e.forward(phi0, dts)
+    assert relerr(ph[:, ::4, ::4], g["phi_nat_sub"]) < SOLVE, st
+    assert np.allclose(l2(ph), g["nrm_phi_nat"], rtol=1e-10)
+    u = np.random.default_rng(int(g["u_seed"])).uniform(-1.0, 1.0, ph.shape)
+    phu, st = e.forward(phi0, dts, u=u)
+    assert relerr(phu[:, ::4, ::4], g["phi_u_sub"]) < SOLVE, st
+    assert np.allclose(l2(phu), g["nrm_phi_u"], rtol=1e-10)
+    tp = (t / (M * dt))[:, None, None]
+    phi_T = _phi_T(N)
+    phi_Q = (1 - tp) * phi0 + tp * phi_T
+    p, q, r, sb = e.backward(phu, t, 5.0, 10.0, phi_Q, phi_T)
+    # A(phi_n) = I - tau L + dt/2 L^2 - dt/2 D L has condition ~ dt/2 (8/h^2)^2 = 3.4e8 at 256^2: two backward-stable
+    # solvers (SuperLU there, CG to a 1e-15 relative residual here) agree to cond * eps ~ 4e-8, not to 1e-9
+    ADJ = 2e-7
+    assert relerr(p[:, ::4, ::4], g["p_sub"]) < ADJ and relerr(r[:, ::4, ::4], g["r_sub"]) < ADJ, sb
+    assert sb["max_lin_relres"] < 1e-14
+    assert np.allclose(l2(p), g["nrm_p"], rtol=ADJ) and np.allclose(l2(q), g["nrm_q"], rtol=1e-5)
+    assert np.allclose(l2(r)[:-1], g["nrm_r"][:-1], rtol=ADJ) and not r[-1].any()
+    J = e.cost(phu, u, phi_Q, phi_T, t, V.make_opt())
+    assert abs(J[4] / float(g["J"]) - 1) < 1e-10
+
+
+def test_config3_full_pgd_iteration_256x400(V, O2):
+    """BASELINE config 3 at size: 256^2, 400 steps of 1/400, one trajectory, one full PGD iteration with the
+    size-independent invariants of the 512^2 test plus the schedule's bookkeeping."""
+    F2 = V.module("Vch_control_2D.Forward2_solver")
+    N, M = 256, 400
+    t, dts = V.time_grid(1.0, 1.0 / M)
+    assert len(dts) == M
+    e = V.Engine2D(Nx=N, Ny=N, batch=1, max_steps=M)
+    phi0 = F2.init_phi_random(N, N, 1e-2, amp=0.1, seed=42)
+    ph, st = e.forward(phi0, dts)
+    wts = np.outer(F2.trapz_weights(N + 1), F2.trapz_weights(N + 1))
+    mass = np.tensordot(ph, wts, axes=([1, 2], [0, 1]))
+    assert np.abs(mass - mass[0]).max() <= 1e-10 * wts.sum()
+    assert np.abs(ph).max() <= 0.99 + 1e-15 and np.isfinite(ph).all()
+    # Newton exit semantics (F2:356-427): every step converged well inside max_iter, Armijo never exhausted
+    assert M < st["newton_iters"] <= 6 * M and st["armijo_trials"] <= 2 * st["linear_solves"]
+    assert st["max_lin_abserr"] <= 1.01e-13 and st["host_syncs"] <= M + 40, st
+    E = e.free_energy_resident(M + 1)
+    assert np.all(np.diff(E) <= 1e-9) and E[-1] < E[0]
+    J0 = e.pgd_init(phi0, _phi_T(N), t, V.make_opt(), ramp=True, T=1.0)
+    res = e.pgd_iterate(1)
+    assert res["iters"] == 1 and res["cost"][0, 0] < J0[0, 4] and 0 <= res["attempts"][0, 0] <= 10
+    assert 0 < res["tracking_error"][0, 0] < 1 and 0 < res["terminal_error"][0, 0] < 2
+    r, u = e.pgd_get("r"), e.pgd_get("u")
+    assert np.isfinite(r).all() and not r[M].any() and u.min() >= -1.0 and u.max() <= 1.0
+    a = res["alpha"][0, 0]
+    zero = np.abs(a * r) <= a * 1e-4
+    assert not u[zero].any() and np.all(u[~zero] != 0)
+    phc = e.pgd_get("phi")
+    massc = np.tensordot(phc, wts, axes=([1, 2], [0, 1]))
+    assert np.abs(massc - massc[0]).max() <= 1e-10 * wts.sum() and np.abs(phc).max() <= 0.99 + 1e-15
+
+
+# ---------------------------------------------------------------------------------------
+# config 5: near-singular start (amp = 1.0, a third of the nodes clipped at +-0.99)
+# ---------------------------------------------------------------------------------------
+def test_stress_128_vs_reference(V, O2):
+    """amp = 1.0 start at 128^2 (the FFT path), dt = 1e-3, 5 steps, against the reference's own run: residual-norm
+    histories of every Newton call (same length, same values down to the round-off floor), number of residual
+    evaluations per step (= 1 + Armijo trials: the step-ceiling / halving path F2:377-419) and the fields."""
+    g = golden("g2d_stress_128.npz")
+    N, M, dt = int(g["N"]), int(g["M"]), float(g["dt"])
+    e = V.Engine2D(Nx=N, Ny=N, max_steps=M)
+    phi = O2.init_phi_random(N, N, 1e-2, amp=1.0, seed=42)
+    assert abs(np.mean(np.abs(phi) >= 0.99) - float(g["clipped_frac0"])) < 1e-12
+    ph, st = e.forward(phi, np.full(M, dt))
+    assert relerr(ph[:, ::2, ::2], g["phi_sub"]) < SOLVE, st
+    assert st["newton_iters"] == int(g["n_hist"].sum())
+    assert st["armijo_trials"] == int(g["res_evals"].sum()) - M, (st, g["res_evals"])     # evaluations = 1 + trials per call
+    # the same five Newton calls one by one, with histories
+    w = np.zeros_like(phi)
+    mu = e.initialize_mu(phi, w)
+    for k in range(M):
+        phi, mu, hist, s1 = e.newton_raphson(phi, mu, w, w, dt)
+        ref = g["hists"][k, :int(g["n_hist"][k])]
+        assert len(hist) == len(ref), (k, hist, ref)
+        big = ref > 1e-7                              # below that the norm is evaluation round-off (|L mu| eps)
+        assert np.allclose(np.asarray(hist)[big], ref[big], rtol=1e-6), (k, hist, ref)
+        assert hist[-1] < 1e-6
+        assert s1["armijo_trials"] == int(g["res_evals"][k]) - 1, (k, s1, g["res_evals"])
+        # clip + mass fix of the march (F2:562-577) are not part of newton_raphson: continue from the march's level,
+        # mu carried as the Newton call returned it (F2:579)
+        phi = ph[k + 1]
+
+
+def test_config5_stress_march_1024(V, O2):
+    """BASELINE config 5 at size: 1024^2, amp = 1.0, dt = 1e-3, 100 steps, one trajectory: the reference's Newton
+    exit semantics (history <= 500 per call, <= 12 Armijo halvings per iteration, F2:394-423), mass conservation,
+    clip band, energy decay; then true residuals of a Newton system and an adjoint system built on the final,
+    near-singular state (|phi| up to 0.99, D up to 1.5e4)."""
+    F2 = V.module("Vch_control_2D.Forward2_solver")
+    N, M = 1024, 100
+    t, dts = V.time_grid(0.1, 1e-3)
+    assert len(dts) == M
+    e = V.Engine2D(Nx=N, Ny=N, batch=1, max_steps=M)
+    phi0 = F2.init_phi_random(N, N, 1e-2, amp=1.0, seed=42)
+    assert 0.25 < np.mean(np.abs(phi0) >= 0.99 - 1e-12) < 0.4
+    ph, st = e.forward(phi0, dts)
+    assert np.isfinite(ph).all() and np.abs(ph).max() <= 0.99 + 1e-15
+    wts = np.outer(F2.trapz_weights(N + 1), F2.trapz_weights(N + 1))
+    lv = list(range(0, M + 1, 10))
+    mass = np.array([np.sum(wts * ph[k]) for k in lv])
+    assert np.abs(mass - mass[0]).max() <= 1e-10 * wts.sum()
+    assert M < st["newton_iters"] <= 500 * M
+    iters = st["newton_iters"] - M                                  # Newton iterations = norms recorded after the first
+    assert st["armijo_trials"] <= 12 * max(iters, 1) + M and st["linear_solves"] <= iters + M, st
+    E = e.free_energy_resident(M + 1)
+    assert E[-1] < E[0]
+    # true residuals on the near-singular final state
+    phi = ph[M]
+    rng = np.random.default_rng(5)
+    a, b_ = rng.standard_normal(phi.shape), rng.standard_normal(phi.shape)
+    dphi, dmu, s1 = e.jacobian_solve(phi, 1e-3, a, b_)
+    top, bot = e.jacobian_apply(phi, 1e-3, dphi, dmu)
+    assert relerr(top, a) < 1e-5 and relerr(bot, b_) < 1e-5, s1      # cond(J) ~ N^4: the forward check amplifies round-off
+    x = rng.standard_normal(phi.shape)
+    y = e.schur_apply(phi, 1e-3, x)                                  # solve(apply(x)) == x: error, not residual
+    rhs_phi, rhs_mu = np.zeros_like(y), y
+    # Schur form of J [dphi; dmu] = [0; y]:  (I/dt + M K) dphi = y
+    d2, _, s2 = e.jacobian_solve(phi, 1e-3, rhs_phi, rhs_mu)
+    assert relerr(d2, x) < 1e-7, s2
+    p, s3 = e.adjoint_solve(phi, 1e-3, a)
+    assert relerr(e.adjoint_apply("A", phi, 1e-3, p), a) < 1e-6, s3
+    # the adjoint sweep over the resident history stays finite and ends with r_M = 0
+    _, _, r, sb = e.backward(None, t, 5.0, 10.0, None, _phi_T(N), want=("r",))
+    assert np.isfinite(r).all() and not r[M].any() and np.abs(r[0]).max() > 0
+
+
+# ---------------------------------------------------------------------------------------
+# config 2: 1D N = 4096, 1000 steps
+# ---------------------------------------------------------------------------------------
+def test_config2_march_and_resident_pgd_4096x1000(V):
+    """BASELINE config 2 at size: the 1000-step march (every Newton call leaves through the line-search-failure
+    return, the round-off-limited regime the reference is in at this size, F1:227-229), mass conservation, clip
+    band; then one device-resident PGD iteration with the loop's invariants."""
+    F1 = V.module("Vch_control_1D.Forward_solver")
+    K1 = V.module("Vch_control_1D.config")
+    G1 = V.module("Vch_control_1D.GD_1D")
+    N, M = 4096, 1000
+    cfg = K1.ForwardSolverConfig(N=N, T=1.0, dt_initial=1e-3)
+    ph, x, t = F1.run_main_simulation(cfg, store_history=True, verbose=False)
+    assert ph.shape == (M + 2, N + 1) and np.array_equal(ph[0], ph[1]) and t[0] == t[1] == 0.0
+    w = F1.trapz_weights(N + 1) / N
+    mass = ph @ w
+    assert np.isfinite(ph).all() and np.abs(mass - mass[0]).max() <= 1e-12 and np.abs(ph).max() < 0.99
+    opt = K1.OptimizationConfig()
+    res = G1.run_optimization_resident(cfg, opt, n_iter=1)
+    assert res["iters"] == 1 and np.isfinite(res["costs"]).all() and 1 <= res["trials"][0] <= 5
+    assert res["costs"][1] < res["costs"][0] or res["trials"][0] == 5        # accepted descent or "return last try"
+    assert res["u"].shape == (M + 2, N + 1) and np.abs(res["u"]).max() <= 1.0
+    assert not res["r"][0].any()                                              # r[0] = 0: the dt <= 0 row (B1:110)
+    assert 0 < res["tracking_error"][0] < 1 and 0 < res["terminal_error"][0] < 2
+
+
+# ---------------------------------------------------------------------------------------
+# launch schedule and inexact Newton
+# ---------------------------------------------------------------------------------------
+def test_one_look_per_step_and_abs_tolerance(V, O2):
+    """The host looks at the device state once per time step in the benign regime (plus the few steps whose
+    schedule was one slot short), the Newton solves stop at the 1e-13 absolute target, and the result does not
+    depend on the schedule: VCH_NO_SPEC=1 (a look after every Newton phase) gives bit-identical histories."""
+    import os
+    N, M = 128, 40
+    t, dts = V.time_grid(M * 1e-3, 1e-3)
+    phi0 = np.stack([O2.init_phi_random(N, N, 1e-2, amp=0.1, seed=42 + i) for i in range(3)])
+    e = V.Engine2D(Nx=N, Ny=N, batch=3, max_steps=M)
+    ph, st = e.forward(phi0, dts)
+    assert st["host_syncs"] <= M + 6, st
+    assert 0 < st["max_lin_abserr"] <= 1.01e-13, st
+    e.close()
+    os.environ["VCH_NO_SPEC"] = "1"
+    try:
+        e2 = V.Engine2D(Nx=N, Ny=N, batch=3, max_steps=M)
+        ph2, st2 = e2.forward(phi0, dts)
+    finally:
+        del os.environ["VCH_NO_SPEC"]
+    assert st2["host_syncs"] >= 2 * M
+    assert np.array_equal(ph, ph2)
+    assert (st["newton_iters"], st["linear_solves"], st["armijo_trials"]) == \
+           (st2["newton_iters"], st2["linear_solves"], st2["armijo_trials"])
+    # against a march with the solves driven to round-off: the absolute stop changes the fields by ~1e-12, not more
+    os.environ["VCH_ABS_TOL"] = "0"
+    try:
+        e3 = V.Engine2D(Nx=N, Ny=N, batch=3, max_steps=M)
+        ph3, st3 = e3.forward(phi0, dts)
+    finally:
+        del os.environ["VCH_ABS_TOL"]
+    assert st3["linear_iters"] > st["linear_iters"]
+    assert st3["newton_iters"] == st["newton_iters"]
+    assert np.max(np.abs(ph3 - ph)) < 1e-10
