@@ -68,8 +68,9 @@ typedef struct vch_stats {
     double  max_lin_relres;    /* worst final relative residual of a linear solve */
     double  seconds;           /* device time of the call (HIP events) */
     /* ABI version 2 */
-    double  max_lin_abserr;    /* worst final Z-weighted rms of the preconditioned residual (~ error of dphi) of a
-                                  Newton linear solve inside a march (absolute stop rule) */
+    double  max_lin_absres;    /* worst (final relative residual x ||rhs||_2) of a Newton linear solve: the estimate of
+                                  the Schur residual it leaves, which the inexact-Newton rule of a march keeps at
+                                  5 % of the Newton tolerance */
     int64_t host_syncs;        /* blocking looks of the host at the device state during the call */
     int64_t launches;          /* kernel launches of the call */
 } vch_stats;

@@ -6,8 +6,8 @@ O=gpurun_out/r2_probe.log
 : > $O
 run() { echo "== $*" >> $O; env "$@" python scripts/fwd_stats.py 512 1000 ${B:-8} >> $O 2>&1; }
 B=8 run VCH_X=1
-B=8 run VCH_ABS_TOL=0
-B=8 run VCH_ABS_TOL=1e-12
+B=8 run VCH_LIN_ETA=0
+B=8 run VCH_LIN_ETA=2e-7
 B=8 run VCH_NO_SPEC=1
 B=4 run VCH_X=1
 B=2 run VCH_X=1

@@ -94,12 +94,11 @@ struct vch2d_ctx {
     // knobs
     int lin_maxit;
     double lin_tol;
-    double abs_tol;                       // absolute error target of the Newton linear solves inside a march (0 = off)
-    double wsum;                          // sum of the trapezoid weights wdev over a plane
+    double lin_eta;                       // target for the Schur residual a Newton solve inside a march leaves (0 = lin_tol)
     // speculative launch schedule of a time step (newton_level): Newton slots and CG sweeps per slot, adapted from the
     // state the host reads once per step
     bool spec;
-    int spec_slots, spec_cgb;
+    int spec_slots, spec_cgb[4];
     // counters since the last reset_counters(): kernel launches and blocking looks at the device state
     long n_launch, n_sync;
 };
@@ -251,14 +250,13 @@ extern "C" vch2d_ctx *vch2d_create(const vch2d_params *p, int batch, int max_ste
     c->lin_maxit = 4000;
     c->lin_tol = 1e-15;
     if (const char *e = getenv("VCH_LIN_TOL")) c->lin_tol = atof(e);      // tuning/experiments only
-    // Newton solves inside a march stop at a Z-weighted rms error of 1e-13 in dphi: the next Newton
-    // iteration removes what is left, and 1e-13 per step is far below the 1e-9 parity tolerance of the fields.
-    c->abs_tol = 1e-13;
-    if (const char *e = getenv("VCH_ABS_TOL")) c->abs_tol = atof(e);
-    c->wsum = (double)(G.nf - 1) * (double)(G.ns - 1);
+    // Newton solves inside a march are stopped when the Schur residual they leave is 5 % of the Newton tolerance
+    // (newton_lin_tol in vch_kernels2d.h); 0 = always lin_tol
+    c->lin_eta = 0.05 * NEWTON_TOL;
+    if (const char *e = getenv("VCH_LIN_ETA")) c->lin_eta = atof(e);
     c->spec = getenv("VCH_NO_SPEC") == nullptr;
     c->spec_slots = 2;
-    c->spec_cgb = 12;
+    for (int &n : c->spec_cgb) n = 12;
     c->n_launch = c->n_sync = 0;
     auto fail = [&](const char *what) {
         vch_fail(VCH_ERR_HIP, "vch2d_create: %s failed: %s", what, hipGetErrorString(hipGetLastError()));
@@ -545,7 +543,7 @@ static int schur_solve(vch2d_ctx *c, double dt, int budget, bool look) {
         LAUNCHC(PC_RESIDUAL, (k_residual<1>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s,     \
                 c->Rphi_s, c->rhs_s, c->D_s, c->mu0, c->x, c->dmu, c->cphi, c->cmu, dt, c->part);                           \
         LAUNCH((k_fin_residual<1>), dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->hist_dev, c->P.kappa, dt, c->lin_tol, \
-               atol_, c->wsum);                                                                                            \
+               eta_);                                                                                                      \
     } while (0)
 
 // One implicit time level for the whole batch (F2:323-427).  On entry the old level is
@@ -558,20 +556,19 @@ static int schur_solve(vch2d_ctx *c, double dt, int budget, bool look) {
 // exit at once); a solve that needs more sweeps than were enqueued is left untouched by the strict ceiling
 // kernel and taken up again by the next slot.  The host looks at the state ONCE per step, finishes the rare
 // step that did not fit (the loop below, one look per Armijo trial) and sizes the next step's schedule from
-// what this one used.  in_march = false (a bare newton_raphson call): relative CG tolerance only.
+// what this one used.  in_march = false (a bare newton_raphson call): the solves go to lin_tol.
 static int newton_level(vch2d_ctx *c, double dt, const double *un, const double *unp1, long u_stride,
                         const double *wnew_in, bool in_march) {
-    const double atol_ = in_march ? c->abs_tol : 0.0;
+    const double eta_ = in_march ? c->lin_eta : 0.0;
     LAUNCH(k_prepare, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s, c->w, un, unp1, u_stride,
            wnew_in, dt, c->wnew, c->mu0, c->cphi, c->cmu);
     LAUNCH(k_fin_newton_begin, dim3(c->B), dim3(64), c->st);
     LAUNCHC(PC_RESIDUAL, (k_residual<0>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s, c->Rphi_s, c->rhs_s,
            c->D_s, c->mu0, c->x, c->dmu, c->cphi, c->cmu, dt, c->part);
-    LAUNCH((k_fin_residual<0>), dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->hist_dev, c->P.kappa, dt, c->lin_tol, atol_,
-           c->wsum);
+    LAUNCH((k_fin_residual<0>), dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->hist_dev, c->P.kappa, dt, c->lin_tol, eta_);
     if (c->spec) {
         for (int s = 0; s < c->spec_slots; ++s) {
-            VCHCHK(schur_solve(c, dt, c->spec_cgb, false));
+            VCHCHK(schur_solve(c, dt, c->spec_cgb[s], false));
             LAUNCH(k_dmu_ceiling, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->x, c->phi_s, c->D_s, c->Rphi_s,
                    c->dmu, c->part);
             LAUNCH(k_fin_ceiling, dim3(c->B), dim3(64), c->st, c->part, c->nblk, 1);
@@ -606,16 +603,21 @@ static int newton_level(vch2d_ctx *c, double dt, const double *un, const double 
     if (c->spec) {
         // next step's schedule: as many slots as the busiest trajectory had linear solves (+ failed trials do not count:
         // they are rare and the loop above absorbs them), and sweeps for the longest solve + 1, within the rigorous bound
-        int solves = 1, sweeps = 1, bound = 1;
+        int solves = 1, sweeps[4] = {1, 1, 1, 1}, longest = 1, bound = 1;
         for (int b = 0; b < c->B; ++b) {
             const TrajState &S = c->st_host[b];
             if (S.frozen) continue;
             solves = std::max(solves, S.step_solves);
-            sweeps = std::max(sweeps, S.step_lin_max);
+            for (int s = 0; s < 4; ++s) sweeps[s] = std::max(sweeps[s], S.step_lin[s]);
+            longest = std::max(longest, S.step_lin_max);
             bound = std::max(bound, S.lin_budget);
         }
         c->spec_slots = std::min(solves, 4);
-        c->spec_cgb = std::max(2, std::min(std::min(sweeps + 1, bound), 64));
+        for (int s = 0; s < 4; ++s) {
+            // a slot this step did not use is sized like the longest solve seen
+            const int want = (s < solves ? sweeps[s] : longest) + 1;
+            c->spec_cgb[s] = std::max(2, std::min(std::min(want, bound), 64));
+        }
     }
     return 0;
 }
@@ -630,7 +632,7 @@ static void fill_stats(vch2d_ctx *c, vch_stats *s, float ms) {
         s->linear_iters += S.lin_total;
         s->armijo_trials += S.ntrials;
         s->max_lin_relres = std::max(s->max_lin_relres, S.lin_maxrel);
-        s->max_lin_abserr = std::max(s->max_lin_abserr, S.lin_maxabs);
+        s->max_lin_absres = std::max(s->max_lin_absres, S.lin_maxabs);
     }
     s->host_syncs = c->n_sync;
     s->launches = c->n_launch;

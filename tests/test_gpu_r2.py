@@ -247,7 +247,9 @@ def test_config3_full_pgd_iteration_256x400(V, O2):
     assert np.abs(ph).max() <= 0.99 + 1e-15 and np.isfinite(ph).all()
     # Newton exit semantics (F2:356-427): every step converged well inside max_iter, Armijo never exhausted
     assert M < st["newton_iters"] <= 6 * M and st["armijo_trials"] <= 2 * st["linear_solves"]
-    assert st["max_lin_abserr"] <= 1.01e-13 and st["host_syncs"] <= M + 40, st
+    # one look per step, plus two for each step whose schedule was a Newton slot short (here the count flips between
+    # one and two solves from step to step; at 512^2 x 1000 the march needs M + 2 looks, test below / bench.py)
+    assert st["host_syncs"] <= 1.25 * M, st
     E = e.free_energy_resident(M + 1)
     assert np.all(np.diff(E) <= 1e-9) and E[-1] < E[0]
     J0 = e.pgd_init(phi0, _phi_T(N), t, V.make_opt(), ramp=True, T=1.0)
@@ -279,7 +281,9 @@ def test_stress_128_vs_reference(V, O2):
     ph, st = e.forward(phi, np.full(M, dt))
     assert relerr(ph[:, ::2, ::2], g["phi_sub"]) < SOLVE, st
     assert st["newton_iters"] == int(g["n_hist"].sum())
-    assert st["armijo_trials"] == int(g["res_evals"].sum()) - M, (st, g["res_evals"])     # evaluations = 1 + trials per call
+    # the reference evaluates the residual at the top of every loop pass (= one norm recorded) and once per Armijo trial
+    assert st["newton_iters"] + st["armijo_trials"] == int(g["res_evals"].sum()), (st, g["res_evals"])
+    assert st["armijo_trials"] == st["newton_iters"] - M                 # every Armijo loop took its first trial
     # the same five Newton calls one by one, with histories
     w = np.zeros_like(phi)
     mu = e.initialize_mu(phi, w)
@@ -290,7 +294,7 @@ def test_stress_128_vs_reference(V, O2):
         big = ref > 1e-7                              # below that the norm is evaluation round-off (|L mu| eps)
         assert np.allclose(np.asarray(hist)[big], ref[big], rtol=1e-6), (k, hist, ref)
         assert hist[-1] < 1e-6
-        assert s1["armijo_trials"] == int(g["res_evals"][k]) - 1, (k, s1, g["res_evals"])
+        assert s1["newton_iters"] + s1["armijo_trials"] == int(g["res_evals"][k]), (k, s1, g["res_evals"])
         # clip + mass fix of the march (F2:562-577) are not part of newton_raphson: continue from the march's level,
         # mu carried as the Newton call returned it (F2:579)
         phi = ph[k + 1]
@@ -368,36 +372,36 @@ def test_config2_march_and_resident_pgd_4096x1000(V):
 # ---------------------------------------------------------------------------------------
 # launch schedule and inexact Newton
 # ---------------------------------------------------------------------------------------
-def test_one_look_per_step_and_abs_tolerance(V, O2):
+def test_one_look_per_step_and_inexact_newton(V, O2):
     """The host looks at the device state once per time step in the benign regime (plus the few steps whose
-    schedule was one slot short), the Newton solves stop at the 1e-13 absolute target, and the result does not
-    depend on the schedule: VCH_NO_SPEC=1 (a look after every Newton phase) gives bit-identical histories."""
+    schedule was one slot short); the result does not depend on the schedule: VCH_NO_SPEC=1 (a look after every
+    Newton phase) gives bit-identical histories.  The inexact-Newton rule (solves stopped when the Schur residual
+    they leave is 5 % of the Newton tolerance) keeps the Newton / Armijo counts of a march whose solves are driven
+    to round-off (VCH_LIN_ETA=0), with fewer CG sweeps, and moves the fields by less than 1e-10."""
     import os
     N, M = 128, 40
     t, dts = V.time_grid(M * 1e-3, 1e-3)
     phi0 = np.stack([O2.init_phi_random(N, N, 1e-2, amp=0.1, seed=42 + i) for i in range(3)])
     e = V.Engine2D(Nx=N, Ny=N, batch=3, max_steps=M)
     ph, st = e.forward(phi0, dts)
-    assert st["host_syncs"] <= M + 6, st
-    assert 0 < st["max_lin_abserr"] <= 1.01e-13, st
+    assert st["host_syncs"] <= M + 8, st
     e.close()
-    os.environ["VCH_NO_SPEC"] = "1"
-    try:
-        e2 = V.Engine2D(Nx=N, Ny=N, batch=3, max_steps=M)
-        ph2, st2 = e2.forward(phi0, dts)
-    finally:
-        del os.environ["VCH_NO_SPEC"]
+
+    def with_env(name, value):
+        os.environ[name] = value
+        try:
+            e2 = V.Engine2D(Nx=N, Ny=N, batch=3, max_steps=M)
+            out = e2.forward(phi0, dts)
+            e2.close()
+            return out
+        finally:
+            del os.environ[name]
+    ph2, st2 = with_env("VCH_NO_SPEC", "1")
     assert st2["host_syncs"] >= 2 * M
     assert np.array_equal(ph, ph2)
-    assert (st["newton_iters"], st["linear_solves"], st["armijo_trials"]) == \
-           (st2["newton_iters"], st2["linear_solves"], st2["armijo_trials"])
-    # against a march with the solves driven to round-off: the absolute stop changes the fields by ~1e-12, not more
-    os.environ["VCH_ABS_TOL"] = "0"
-    try:
-        e3 = V.Engine2D(Nx=N, Ny=N, batch=3, max_steps=M)
-        ph3, st3 = e3.forward(phi0, dts)
-    finally:
-        del os.environ["VCH_ABS_TOL"]
-    assert st3["linear_iters"] > st["linear_iters"]
-    assert st3["newton_iters"] == st["newton_iters"]
+    counts = lambda s: (s["newton_iters"], s["linear_solves"], s["armijo_trials"])
+    assert counts(st) == counts(st2) and st["linear_iters"] == st2["linear_iters"]
+    ph3, st3 = with_env("VCH_LIN_ETA", "0")
+    assert st3["linear_iters"] > st["linear_iters"], (st, st3)
+    assert counts(st3) == counts(st), (st, st3)
     assert np.max(np.abs(ph3 - ph)) < 1e-10
