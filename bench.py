@@ -44,15 +44,18 @@ FP64_MFMA_PEAK_TF = 78.6     # = 1/2 of the 157.3 TF FP32 vector/matrix peak of 
 
 # Algorithmic bytes per node per launch (fp64 fields read + written once).
 ALG_BYTES = {
-    "schur_p": 72.0,         # z, q, p_old, D, x -> x, z', p, v
+    "cg_rows_fwd": 72.0,     # z, q, p_old, D, x -> x, z', p', E_rows(Delta p')   (first pass of a CG sweep)
+    "cg_rows_fwd_first": 40.0,   # z, D -> x (zeroed), p, E_rows(Delta p)
+    "schur_p": 72.0,         # GEMM-DCT grids only: z, q, p_old, D, x -> x, z', p, v
     "schur_p_first": 40.0,   # z, D -> x (zeroed), p, v
     "dct_rows_fwd": 16.0,    # field -> field
     "dct_cols": 16.0,        # field -> field (forward transform, multiplier, inverse transform in LDS)
     "dct_rows_inv": 32.0,    # field, D, other -> field (+ the CG dot products)
     "residual": 88.0,        # trial form: phi, dphi, mu, dmu, c_phi, c_mu -> phi_t, mu_t, R_phi, rhs, D
-    "adj_q": 32.0, "cg_update": 48.0, "adj_rhs": 72.0,
+    "adj_q": 64.0,           # first pass of an adjoint CG sweep (k_adj_rows_fwd): r, q, ph_old, y -> y, r', ph', E_rows(ph')
+    "cg_update": 24.0, "adj_rhs": 72.0,
 }
-PMC_NAMES = {"schur_p": "k_schur_p<0>", "dct_rows_fwd": "k_dct_rows<0, 1024, 10>", "dct_cols": "k_dct_cols<1024, 10>",
+PMC_NAMES = {"cg_rows_fwd": "k_cg_rows_fwd<0, 1024, 10>", "schur_p": "k_schur_p<0>", "dct_rows_fwd": "k_dct_rows<0, 1024, 10>", "dct_cols": "k_dct_cols<1024, 10>",
              "dct_rows_inv": "k_dct_rows<3, 1024, 10>", "residual": "k_residual<1>", "adj_q": "k_adj_q"}
 
 
@@ -336,8 +339,12 @@ def run(a, world, rank, local, dist):
         ranked = sorted((k for k in tot if k in alg), key=lambda k: -tot[k])
         roof = roof_of(ranked[0]) if ranked else None
         extra["roofline_kernels"] = [roof_of(k) for k in ranked]
-        if "schur_p" in tot:
-            extra["roofline_newton_stencil"] = roof_of("schur_p")
+        # the Newton stencil kernel of the path: the residual / Schur right-hand side evaluation (the CG sweeps of
+        # power-of-two grids apply the operator in the DCT basis and contain no stencil; GEMM-DCT grids use k_schur_p)
+        for k in ("schur_p", "residual"):
+            if k in tot:
+                extra["roofline_newton_stencil"] = roof_of(k)
+                break
         extra["dct_path"] = ("in-LDS Stockham FFT of the even extension, plan 8x8x4x4 at 512^2 (8x8x8 / 8x8x8x4 at 256^2 / 1024^2)"
                              if engs[0].uses_fft else "MFMA f64 16x16x4 GEMM with DCT matrices")
         extra["roofline_note"] = ("one extra PGD iteration after the timed region, all contexts of the rank running; "

@@ -40,6 +40,7 @@ struct vch2d_ctx {
     double *cg_p[2], *cg_v, *cg_q;        // CG search directions / operator images
     double *cg_z2;                        // second residual buffer of the forward CG (z ping-pongs r <-> cg_z2)
     double *gpart2;                       // second half of gpart
+    double *gpart3;                       // [2][B][gnblk + ns] partials of <z',z'>_Z of the stencil-free sweep
     double *gpart;                        // [B][gnblk] partials written by the GEMM epilogue
     int gnblk;
     double *tmp[6];
@@ -114,7 +115,8 @@ struct vch2d_ctx {
 
 // Kernel classes for the in-situ timing of vch2d_prof_begin/_end.
 enum { PC_SCHUR_P = 0, PC_GEMM = 1, PC_RESIDUAL = 2, PC_ADJ_Q = 3, PC_CG_UPDATE = 4, PC_ADJ_RHS = 5, PC_COST = 6,
-       PC_PROX = 7, PC_DCT_R0 = 8, PC_DCT_C = 9, PC_DCT_R3 = 10, PC_SCHUR_P1 = 11, PC_NCLS = 12 };
+       PC_PROX = 7, PC_DCT_R0 = 8, PC_DCT_C = 9, PC_DCT_R3 = 10, PC_SCHUR_P1 = 11, PC_CG_ROWS = 12, PC_CG_ROWS1 = 13,
+       PC_NCLS = 14 };
 
 // launch with an event pair around it when profiling is on (events are recorded on the
 // engine's own stream, the one the kernel is launched on)
@@ -278,6 +280,7 @@ extern "C" vch2d_ctx *vch2d_create(const vch2d_params *p, int batch, int max_ste
     c->gnblk = ((G.nf + GN - 1) / GN) * ((G.ns + GM - 1) / GM);
     if (dalloc(&c->gpart, 2 * (size_t)batch * (c->gnblk + G.ns), c->stream)) return fail("hipMalloc");
     c->gpart2 = c->gpart + (size_t)batch * (c->gnblk + G.ns);
+    if (dalloc(&c->gpart3, 4 * (size_t)batch * (c->gnblk + G.ns), c->stream)) return fail("hipMalloc");
     if (dalloc(&c->hist_dev, (size_t)batch * HIST_CAP, c->stream)) return fail("hipMalloc");
     if (dalloc(&c->alpha_dev, batch, c->stream) || dalloc(&c->J_dev, 5 * (size_t)batch, c->stream)) return fail("hipMalloc");
     if (dalloc(&c->J_ring_dev, (size_t)J_RING * 5 * batch, c->stream)) return fail("hipMalloc");
@@ -368,7 +371,7 @@ extern "C" void vch2d_destroy(vch2d_ctx *c) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     double *all[] = {c->phi_s, c->mu_s, c->Rphi_s, c->rhs_s, c->D_s, c->w, c->wnew, c->mu0, c->cphi, c->cmu, c->x,
-                     c->r, c->dmu, c->t1, c->t2, c->cg_p[0], c->cg_p[1], c->cg_v, c->cg_q, c->cg_z2, c->gpart, c->tmp[0], c->tmp[1], c->tmp[2], c->tmp[3], c->tmp[4], c->tmp[5],
+                     c->r, c->dmu, c->t1, c->t2, c->cg_p[0], c->cg_p[1], c->cg_v, c->cg_q, c->cg_z2, c->gpart, c->gpart3, c->tmp[0], c->tmp[1], c->tmp[2], c->tmp[3], c->tmp[4], c->tmp[5],
                      c->phiT, c->phi0, c->wts_mass, c->W_cost, c->part, c->hist_dev, c->alpha_dev, c->J_dev, c->Q1f,
                      c->Q2f, c->Q1s, c->Q2s, c->mf, c->ms, c->phi_hist, c->u_hist, c->u_trial, c->phi_trial, c->phiQ,
                      c->r_hist, c->p_hist, c->q_hist, c->cost_part, c->cost_lvl, c->tfrac_dev};
@@ -407,27 +410,27 @@ extern "C" int vch2d_batch(const vch2d_ctx *c) { return c ? c->B : VCH_ERR_ARG; 
 // ------------------------------------------------------------------------------------
 // fast-diagonalisation preconditioner:  out = (c0 + m (c1a + c1b dbar + c2 m))^-1 in
 //   last: 0 store; 3 store + partial of sum W (D[slot] - dbar) other*out into c->gpart
-//         (other == NULL: out*out)
+//         (other == NULL: out*out); 4 (FFT path only): out = other + result
 // ------------------------------------------------------------------------------------
 static int precond(vch2d_ctx *c, const double *in, long in_slot_stride, double *out, int last, const double *other,
                    double c0, double c1a, double c1b, double c2, int gate) {
     const Geom &G = c->G;
     const int ns = G.ns, nf = G.nf;
     dim3 g((nf + GN - 1) / GN, (ns + GM - 1) / GM, c->B);
-    SpecArgs sp{c0, c1a, c1b, c2, c->ms, c->mf, other, c->D_s, c->slot_stride, c->gpart, c->gpart2};
+    SpecArgs sp{c0, c1a, c1b, c2, c->ms, c->mf, other, c->D_s, c->slot_stride, c->gpart, c->gpart2, 0};
     if (c->use_fft) {
         const double scale = 1.0 / (4.0 * (double)c->fax.N * (double)c->sax.N);
         // C = complex doubles per workgroup: 1024 (one wavefront) unless the FFT is longer
 #define DCT_ROWS(EPI_, C_, LG_, in_, iss_, out_)                                                                \
     do {                                                                                                        \
         const int rpw = 2 * (C_ >> c->fax.logL);                                                                \
-        LAUNCHC(((EPI_) == 3 ? PC_DCT_R3 : PC_DCT_R0), (k_dct_rows<EPI_, C_, LG_>), dim3((ns + rpw - 1) / rpw, 1, c->B), dim3(FftThreads<C_>::T), G, \
+        LAUNCHC(((EPI_) >= 3 ? PC_DCT_R3 : PC_DCT_R0), (k_dct_rows<EPI_, C_, LG_>), dim3((ns + rpw - 1) / rpw, 1, c->B), dim3(FftThreads<C_, LG_>::T), G, \
                 c->fax, in_, iss_, out_, 1.0, sp, c->st, gate);                                                 \
     } while (0)
 #define DCT_COLS(C_, LG_)                                                                                       \
     do {                                                                                                        \
         const int cpw = 2 * (C_ >> c->sax.logL);                                                                \
-        LAUNCHC(PC_DCT_C, (k_dct_cols<C_, LG_>), dim3((nf + cpw - 1) / cpw, 1, c->B), dim3(FftThreads<C_>::T), G, \
+        LAUNCHC(PC_DCT_C, (k_dct_cols<C_, LG_>), dim3((nf + cpw - 1) / cpw, 1, c->B), dim3(FftThreads<C_, LG_>::T), G, \
                 c->sax, (const double *)c->t1, c->t2, scale, sp, c->st, gate);                                  \
     } while (0)
         // FFT lengths 512 / 1024 / 2048 (grids 256^2, 512^2, 1024^2) are compiled with a constant length
@@ -456,6 +459,7 @@ static int precond(vch2d_ctx *c, const double *in, long in_slot_stride, double *
             if (last == 3) DCTH_ROWS(3, (const double *)c->t2, 0L, out);
             else DCTH_ROWS(0, (const double *)c->t2, 0L, out);
         } else if (last == 3) DCT_ROWS_ANY(3, (const double *)c->t2, 0L, out);
+        else if (last == 4) DCT_ROWS_ANY(4, (const double *)c->t2, 0L, out);
         else DCT_ROWS_ANY(0, (const double *)c->t2, 0L, out);
         return 0;
     }
@@ -475,6 +479,22 @@ static int precond(vch2d_ctx *c, const double *in, long in_slot_stride, double *
     else
         LAUNCHC(PC_GEMM, (k_gemm<false, 0>), g, dim3(256), ns, nf, nf, c->t1, (long)G.pitch, G.plane, 0L, c->Q2f, (long)nf, 0L, out,
                (long)G.pitch, G.plane, sp, c->st, gate);
+    return 0;
+}
+
+// Passes 2 and 3 of a stencil-free forward CG sweep (after k_cg_rows_fwd has left E_rows(Delta p) in c->t1):
+// column transforms with the multiplier m / P(m), then q = p + E_rows(.) with the partials of <p,q>_Z, <q,q>_Z.
+static int sweep_tail(vch2d_ctx *c, const double *p, double *q, double c0, double c2, int gate) {
+    const Geom &G = c->G;
+    const int ns = G.ns, nf = G.nf;
+    SpecArgs sp{c0, 0.0, 1.0, c2, c->ms, c->mf, p, c->D_s, c->slot_stride, c->gpart, c->gpart2, 1};
+    const double scale = 1.0 / (4.0 * (double)c->fax.N * (double)c->sax.N);
+    if (c->sax.logL == 10) DCT_COLS(1024, 10);
+    else if (c->sax.logL == 9) DCT_COLS(1024, 9);
+    else if (c->sax.logL < 10) DCT_COLS(1024, 0);
+    else if (c->sax.logL == 11) DCT_COLS(2048, 11);
+    else DCT_COLS(4096, 0);
+    DCT_ROWS_ANY(4, (const double *)c->t2, 0L, q);
     return 0;
 }
 
@@ -507,13 +527,37 @@ static int schur_solve(vch2d_ctx *c, double dt, int budget, bool look) {
     double *zb[2] = {c->r, c->cg_z2};               // z_k lives in zb[k & 1]
     VCHCHK(precond(c, c->rhs_s, c->slot_stride, zb[0], 3, nullptr, c0, 0.0, 1.0, c2, 1));      // z = P^-1 rhs, <z,z>_Z
     LAUNCH(k_fin_cg_init, dim3(c->B), dim3(64), c->st, c->gpart, c->gnblk);
+    const bool spectral = c->use_fft && !c->half_f && !c->half_s;      // stencil-free sweep (k_cg_rows_fwd)
     int done = 0;
     while (done < budget) {
         const int chunk = look ? std::min(budget - done, CG_CHUNK) : budget - done;
         for (int j = 0; j < chunk; ++j, ++done) {
             double *pn = c->cg_p[done & 1], *po = c->cg_p[(done + 1) & 1];
-            // iteration `done`: the reduction point of iteration done-1 is resolved inside the kernel and its
-            // step goes into x and z on the way (see k_schur_p); 4 launches per iteration
+            if (spectral) {
+                // sweep `done`: the reduction point of sweep done-1 is resolved inside the first kernel and its step goes
+                // into x and z on the way into the row transform; 3 launches per sweep, no stencil
+                CgSweepArgs a{done == 0 ? zb[0] : zb[(done + 1) & 1], c->cg_q, po, c->x, zb[done & 1], pn, c->D_s, c->slot_stride,
+                              c->gpart, c->gpart2, c->gpart3, done, c->lin_maxit, c->B};
+#define CG_ROWS(FIRST_, C_, LG_)                                                                                          \
+    do {                                                                                                                  \
+        const int rpw = 2 * (C_ >> c->fax.logL);                                                                          \
+        LAUNCHC((FIRST_ ? PC_CG_ROWS1 : PC_CG_ROWS), (k_cg_rows_fwd<FIRST_, C_, LG_>), dim3((c->G.ns + rpw - 1) / rpw, 1, c->B), \
+                dim3(FftThreads<C_, LG_>::T), c->G, c->fax, a, c->t1, c->st);                                             \
+    } while (0)
+#define CG_ROWS_ANY(FIRST_)                                       \
+    do {                                                          \
+        if (c->fax.logL == 10) CG_ROWS(FIRST_, 1024, 10);         \
+        else if (c->fax.logL == 9) CG_ROWS(FIRST_, 1024, 9);      \
+        else if (c->fax.logL < 10) CG_ROWS(FIRST_, 1024, 0);      \
+        else if (c->fax.logL == 11) CG_ROWS(FIRST_, 2048, 11);    \
+        else CG_ROWS(FIRST_, 4096, 0);                            \
+    } while (0)
+                if (done == 0) CG_ROWS_ANY(1);
+                else CG_ROWS_ANY(0);
+                VCHCHK(sweep_tail(c, pn, c->cg_q, c0, c2, 2 + (done & 1)));      // q = P^-1 A p, <p,q>_Z, <q,q>_Z
+                continue;
+            }
+            // GEMM-DCT grids: the 13-point operator as a stencil, fused with the CG vector updates; 4 launches + the GEMMs
             if (done == 0) {
                 LAUNCHC(PC_SCHUR_P1, (k_schur_p<1>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, zb[0], c->cg_q, po, c->D_s, dt,
                         c->x, zb[1], pn, c->cg_v, c->part, (const double *)c->gpart, (const double *)c->gpart2, c->gnblk, 0,
@@ -532,8 +576,13 @@ static int schur_solve(vch2d_ctx *c, double dt, int budget, bool look) {
         }
     }
     // the reduction point of the last enqueued iteration, then its step
-    LAUNCH(k_fin_cg_step, dim3(c->B), dim3(192), c->st, c->gpart, c->gpart2, c->gnblk, c->part, c->nblk, (done - 1) & 1,
-           done - 1 >= 1 ? 1 : 0, (done - 1) & 1, (done - 1) & 1, c->lin_tol, c->lin_maxit);
+    if (spectral)
+        LAUNCH(k_fin_cg_step3, dim3(c->B), dim3(192), c->st, (const double *)c->gpart, (const double *)c->gpart2,
+               (const double *)(c->gpart3 + (size_t)((done - 1) & 1) * c->B * c->gnblk), c->gnblk, done - 1 >= 1 ? 1 : 0, (done - 1) & 1,
+               (done - 1) & 1, c->lin_maxit);
+    else
+        LAUNCH(k_fin_cg_step, dim3(c->B), dim3(192), c->st, c->gpart, c->gpart2, c->gnblk, c->part, c->nblk, (done - 1) & 1,
+               done - 1 >= 1 ? 1 : 0, (done - 1) & 1, (done - 1) & 1, c->lin_tol, c->lin_maxit);
     LAUNCHC(PC_CG_UPDATE, k_cg_finish, c->grid, dim3(NTH), c->G, c->st, c->cg_p[0], c->cg_p[1], c->x);
     return 0;
 }
@@ -789,10 +838,70 @@ extern "C" int vch2d_jacobian_solve(vch2d_ctx *c, const double *phi_new, double 
 // ------------------------------------------------------------------------------------
 // CG for A(phi_n) x = rhs, right-preconditioned, weighted inner product W / (D_n - dbar);
 // initial guess = current content of c->x.  Buffers: rhs = c->cphi, D_n = c->cmu, r = c->r.
-static int adjoint_solve_cg(vch2d_ctx *c, double dt, int budget) {
-    double *ph = c->cg_p[0], *pv = c->cg_p[1], *q = c->cg_q;
+//
+// Power-of-two grids: the stencil-free single-reduction form of vch_fft.h (k_adj_rows_fwd): x = x0 + P^-1 y, three
+// launches per sweep.  `look` = the host may look at the state every CG_CHUNK sweeps of a long solve.  A solve that the
+// enqueued sweeps do not finish keeps lin_active set; the next k_fin_lin_begin counts it (lin_unconv).
+static int adjoint_solve_cg(vch2d_ctx *c, double dt, int budget, bool look) {
+    const bool spectral = c->use_fft && !c->half_f && !c->half_s;
     // r = rhs - A x0, <r,r>_Z', ||r||_2
     LAUNCH((k_adj_op<1>), c->grid, dim3(NTH), c->G, c->P, c->st, c->x, c->cmu, c->cphi, dt, c->r, c->part);
+    if (spectral) {
+        if (budget <= 0) return 0;
+        const double cadj = 0.5 * dt;
+        const Geom &G = c->G;
+        const int ns = G.ns, nf = G.nf;
+        double *rb[2] = {c->r, c->cg_z2}, *y = c->cg_v;
+        LAUNCH(k_fin_adj_init, dim3(c->B), dim3(64), c->st, (const double *)c->part, c->nblk, c->lin_tol, c->lin_maxit);
+        int done = 0;
+        while (done < budget) {
+            const int chunk = look ? std::min(budget - done, CG_CHUNK) : budget - done;
+            for (int j = 0; j < chunk; ++j, ++done) {
+                double *pn = c->cg_p[done & 1], *po = c->cg_p[(done + 1) & 1];
+                AdjSweepArgs a{done == 0 ? rb[0] : rb[(done + 1) & 1], c->cg_q, po, y, rb[done & 1], pn, c->cmu,
+                               c->gpart, c->gpart2, c->gpart3, done, c->lin_maxit, c->B};
+#define ADJ_ROWS(FIRST_, C_, LG_)                                                                                       \
+    do {                                                                                                                \
+        const int rpw = 2 * (C_ >> c->fax.logL);                                                                        \
+        LAUNCHC(PC_ADJ_Q, (k_adj_rows_fwd<FIRST_, C_, LG_>), dim3((ns + rpw - 1) / rpw, 1, c->B), dim3(FftThreads<C_, LG_>::T), G, \
+                c->fax, a, c->t1, c->st);                                                                               \
+    } while (0)
+#define ADJ_ROWS_ANY(FIRST_)                                       \
+    do {                                                           \
+        if (c->fax.logL == 10) ADJ_ROWS(FIRST_, 1024, 10);         \
+        else if (c->fax.logL == 9) ADJ_ROWS(FIRST_, 1024, 9);      \
+        else if (c->fax.logL < 10) ADJ_ROWS(FIRST_, 1024, 0);      \
+        else if (c->fax.logL == 11) ADJ_ROWS(FIRST_, 2048, 11);    \
+        else ADJ_ROWS(FIRST_, 4096, 0);                            \
+    } while (0)
+                if (done == 0) ADJ_ROWS_ANY(1);
+                else ADJ_ROWS_ANY(0);
+                // q = ph + c Delta (M P^-1 ph), <ph,q>_Z', <q,q>_Z'
+                SpecArgs sp{1.0, c->P.tau, cadj, cadj, c->ms, c->mf, pn, c->cmu, 0L, c->gpart, c->gpart2, 1, cadj};
+                const double scale = 1.0 / (4.0 * (double)c->fax.N * (double)c->sax.N);
+                const int gate = 2 + (done & 1);
+                if (c->sax.logL == 10) DCT_COLS(1024, 10);
+                else if (c->sax.logL == 9) DCT_COLS(1024, 9);
+                else if (c->sax.logL < 10) DCT_COLS(1024, 0);
+                else if (c->sax.logL == 11) DCT_COLS(2048, 11);
+                else DCT_COLS(4096, 0);
+                DCT_ROWS_ANY(5, (const double *)c->t2, 0L, c->cg_q);
+            }
+            if (done < budget) {
+                LAUNCH(k_cg_publish, dim3((c->B + 63) / 64), dim3(64), c->st, (done - 1) & 1, c->B);
+                VCHCHK(sync_state(c));
+                if (!any_lin_active(c)) break;
+            }
+        }
+        LAUNCH(k_fin_adj_step, dim3(c->B), dim3(192), c->st, (const double *)c->gpart, (const double *)c->gpart2,
+               (const double *)(c->gpart3 + (size_t)((done - 1) & 1) * c->B * c->gnblk * 2), c->gnblk, done - 1 >= 1 ? 1 : 0,
+               (done - 1) & 1, (done - 1) & 1, c->lin_maxit);
+        LAUNCHC(PC_CG_UPDATE, k_cg_finish, c->grid, dim3(NTH), c->G, c->st, c->cg_p[0], c->cg_p[1], y);       // pending y += alpha ph
+        // x = x0 + P^-1 y for the trajectories whose solve took place
+        VCHCHK(precond(c, y, 0, c->x, 4, c->x, 1.0, c->P.tau, cadj, cadj, 4));
+        return 0;
+    }
+    double *ph = c->cg_p[0], *pv = c->cg_p[1], *q = c->cg_q;
     LAUNCH(k_fin_cg_beta, dim3(c->B), dim3(64), c->st, c->part, c->nblk, 1, c->lin_tol, c->lin_maxit, 1);
     int done = 0;
     while (done < budget) {
@@ -806,7 +915,7 @@ static int adjoint_solve_cg(vch2d_ctx *c, double dt, int budget) {
             LAUNCHC(PC_CG_UPDATE, k_cg_update_adj, c->grid, dim3(NTH), c->G, c->st, pv, q, c->cmu, c->x, c->r, c->part);
             LAUNCH(k_fin_cg_beta, dim3(c->B), dim3(64), c->st, c->part, c->nblk, 1, c->lin_tol, c->lin_maxit, 0);
         }
-        if (done < budget) {
+        if (done < budget && look) {
             VCHCHK(sync_state(c));
             if (!any_lin_active(c)) break;
         }
@@ -840,7 +949,7 @@ extern "C" int vch2d_adjoint_solve(vch2d_ctx *c, const double *phi_n, double dt,
     LAUNCH(k_fin_lin_begin, dim3(c->B), dim3(64), c->st, c->part, c->nblk, 0, c->P.tau, c->P.kappa, dt, c->lin_tol);
     LAUNCH(k_fill, c->grid, dim3(NTH), c->G, c->x, 0.0);
     VCHCHK(sync_state(c));
-    VCHCHK(adjoint_solve_cg(c, dt, cg_budget(c, false)));
+    VCHCHK(adjoint_solve_cg(c, dt, cg_budget(c, false), true));
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     VCHCHK(d2h(c, p_out, c->x, c->B));
     VCHCHK(sync_state(c));
@@ -950,8 +1059,13 @@ extern "C" int vch2d_forward(vch2d_ctx *c, const double *phi0, const double *u, 
 // adjoint sweep (B2:75-246)
 // ------------------------------------------------------------------------------------
 // phi history in phi_hist_dev ([B][Mmax+1][plane]); targets phiQ_dev (same layout) or NULL, phiT_dev [B][plane] or NULL.
-static int backward_core(vch2d_ctx *c, const double *phi_hist_dev, int M, const double *t_hist, double b1, double b2,
-                         const double *phiQ_dev, const double *phiT_dev, double *r_out, double *p_out, double *q_out) {
+// Launch schedule: the sweeps a solve needs change slowly along the sweep (the start p_{n+1} is a good guess), so the
+// host looks at the device state only every ADJ_LOOK steps and enqueues (longest solve so far) + 1 sweeps per step, within
+// the rigorous bound; solves are gated per trajectory, and one that its sweeps did not finish is counted on the device
+// (lin_unconv).  safe = true: a look and the rigorous budget at every step (the fallback of backward_core).
+constexpr int ADJ_LOOK = 8;
+static int backward_pass(vch2d_ctx *c, const double *phi_hist_dev, int M, const double *t_hist, double b1, double b2,
+                         const double *phiQ_dev, const double *phiT_dev, double *r_out, double *p_out, double *q_out, bool safe) {
     const long hs = hist_stride(c);
     const Geom &G = c->G;
     double *rhs = c->cphi, *Dn = c->cmu, *rcur = c->wnew;
@@ -961,7 +1075,9 @@ static int backward_core(vch2d_ctx *c, const double *phi_hist_dev, int M, const 
     LAUNCH(k_adj_setup, c->grid, dim3(NTH), G, c->P, (const double *)nullptr, (const double *)rhs, Dn, c->part);
     LAUNCH(k_fin_lin_begin, dim3(c->B), dim3(64), c->st, c->part, c->nblk, 0, c->P.tau, c->P.kappa, 0.0, c->lin_tol);
     LAUNCH(k_fill, c->grid, dim3(NTH), G, c->x, 0.0);
-    VCHCHK(adjoint_solve_cg(c, 0.0, 3));
+    VCHCHK(adjoint_solve_cg(c, 0.0, 3, false));
+    int sweeps = -1, steps_since_look = 0;
+    bool first_solve = true;
     LAUNCH(k_adj_finish, c->grid, dim3(NTH), G, c->x, (const double *)nullptr, qa, rcur, 0.0, 0.0,
            r_out ? r_out + (long)M * G.plane : (double *)nullptr, p_out ? p_out + (long)M * G.plane : (double *)nullptr,
            q_out ? q_out + (long)M * G.plane : (double *)nullptr, hs);
@@ -980,14 +1096,39 @@ static int backward_core(vch2d_ctx *c, const double *phi_hist_dev, int M, const 
                phi_hist_dev + (long)(n + 1) * G.plane, phiQ_dev ? phiQ_dev + (long)n * G.plane : (const double *)nullptr,
                phiQ_dev ? phiQ_dev + (long)(n + 1) * G.plane : (const double *)nullptr, hs, dtn, b1, rhs, Dn, c->part);
         LAUNCH(k_fin_lin_begin, dim3(c->B), dim3(64), c->st, c->part, c->nblk, 0, c->P.tau, c->P.kappa, dtn, c->lin_tol);
-        VCHCHK(sync_state(c));
-        VCHCHK(adjoint_solve_cg(c, dtn, cg_budget(c, false)));
+        if (safe || steps_since_look >= ADJ_LOOK || sweeps < 0) {
+            VCHCHK(sync_state(c));
+            steps_since_look = 0;
+            int longest = 0;
+            for (int b = 0; b < c->B; ++b) longest = std::max(longest, c->st_host[b].step_lin_max);
+            const int bound = cg_budget(c, false);
+            // the first solve of the sweep has nothing to go by: rigorous bound, with looks
+            sweeps = (safe || first_solve) ? bound : std::max(2, std::min(longest + 1, bound));
+        }
+        ++steps_since_look;
+        VCHCHK(adjoint_solve_cg(c, dtn, sweeps, safe || first_solve));
+        if (first_solve) { sweeps = -1; first_solve = false; }       // look again right after it
         const double den = c->P.gamma + 0.5 * dtn;
         LAUNCH(k_adj_finish, c->grid, dim3(NTH), G, c->x, qa, qb, rcur, (c->P.gamma - 0.5 * dtn) / den, (0.5 * dtn) / den, rl,
                pl, ql, hs);
         std::swap(qa, qb);
     }
     return 0;
+}
+
+static int backward_core(vch2d_ctx *c, const double *phi_hist_dev, int M, const double *t_hist, double b1, double b2,
+                         const double *phiQ_dev, const double *phiT_dev, double *r_out, double *p_out, double *q_out) {
+    VCHCHK(backward_pass(c, phi_hist_dev, M, t_hist, b1, b2, phiQ_dev, phiT_dev, r_out, p_out, q_out, false));
+    VCHCHK(sync_state(c));
+    bool redo = false;
+    for (int b = 0; b < c->B; ++b) {
+        const TrajState &S = c->st_host[b];
+        // a solve that ran out of sweeps above round-off level: the schedule was too short somewhere
+        if ((S.lin_unconv > 0 && S.lin_maxrel > 1e-12) || (S.lin_active && S.lin_rel > 1e-12)) redo = true;
+    }
+    if (!redo) return 0;
+    VCHCHK(reset_counters(c));
+    return backward_pass(c, phi_hist_dev, M, t_hist, b1, b2, phiQ_dev, phiT_dev, r_out, p_out, q_out, true);
 }
 
 extern "C" int vch2d_backward(vch2d_ctx *c, const double *phi_hist, int M, const double *t_hist, double hx, double hy,
@@ -1547,7 +1688,7 @@ extern "C" int vch2d_debug_fft_phases(vch2d_ctx *c, long long *out, int cap) {
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_fft_dbg), &dev, sizeof(dev)));
     SpecArgs sp{1.0, 0.0, 0.0, 0.0, c->ms, c->mf, nullptr, c->D_s, c->slot_stride, c->gpart, c->gpart2};
     for (int rep = 0; rep < 3; ++rep)
-        LAUNCH((k_dct_rows<0, 1024, 10>), dim3(nblk, 1, c->B), dim3(FftThreads<1024>::T), c->G, c->fax, (const double *)c->tmp[0], 0L,
+        LAUNCH((k_dct_rows<0, 1024, 10>), dim3(nblk, 1, c->B), dim3(FftThreads<1024, 10>::T), c->G, c->fax, (const double *)c->tmp[0], 0L,
                c->t1, 1.0, sp, c->st, 0);
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(out, dev, sizeof(long long) * n * 4, hipMemcpyDeviceToHost));

@@ -81,9 +81,17 @@ __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
 #ifndef FFT_COLS_EMIT
 #define FFT_COLS_EMIT 1
 #endif
+// FFT_W64 (off): the 1024-point FFT (512^2 grid) done by ONE wavefront with the plan 16 x 8 x 8: a radix-16 butterfly per
+// lane fed from global memory, then two radix-8 passes with two butterflies per lane -- two LDS exchanges instead of
+// three, no workgroup barrier that ever waits for another wave, the last pass emitted from registers.  Its radix-16
+// pass writes index 16 j + r, for which the 16-byte slot within a 256-byte row of banks is XOR-ed with index bits 4..7.
+#ifndef FFT_W64
+#define FFT_W64 0      // measured slower than the two-wave 8x8x4x4 plan (profiles/r02_fft_variants.txt): opt-in A/B knob
+#endif
 template <int LOGL>
 __device__ __forceinline__ int swz(int c) {
 #if FFT_R8 && FFT_SWZ && !FFT_PAD
+    if (LOGL == 10 && FFT_W64) return c ^ ((c >> 4) & 15);
     if (LOGL >= 9 && LOGL <= 11) return c ^ ((c >> 3) & 7);
 #endif
     return PADC(c);
@@ -99,9 +107,9 @@ struct FftLds {
 #ifndef FFT_BPT
 #define FFT_BPT 2
 #endif
-template <int C>
+template <int C, int LOGL = 0>
 struct FftThreads {
-    static constexpr int T = C / (4 * FFT_BPT);
+    static constexpr int T = (LOGL == 10 && C == 1024 && FFT_W64 && FFT_R8) ? 64 : C / (4 * FFT_BPT);
 };
 
 // LOGL > 0: log2 of the FFT length is a compile-time constant (all index arithmetic folds and the
@@ -124,19 +132,131 @@ struct FftNoIngest {
     __device__ __forceinline__ double2 operator()(int) const { return make_double2(0.0, 0.0); }
 };
 
+// ---- one-wavefront 1024-point FFT (plan 16 x 8 x 8) ----
+__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+
+// 8-point DFT, natural order in and out (o_m = sum_n a_n exp(-2 pi i n m / 8))
+__device__ __forceinline__ void dft8(const double2 (&a)[8], double2 (&o)[8]) {
+    constexpr double RH = 0.70710678118654752440;
+    double2 bb[4], cc[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        bb[n] = cadd(a[n], a[n + 4]);
+        cc[n] = csub(a[n], a[n + 4]);
+    }
+    cc[1] = make_double2(RH * (cc[1].x + cc[1].y), RH * (cc[1].y - cc[1].x));      // * (1 - i)/sqrt 2
+    cc[2] = make_double2(cc[2].y, -cc[2].x);                                       // * (-i)
+    cc[3] = make_double2(RH * (cc[3].y - cc[3].x), -RH * (cc[3].x + cc[3].y));     // * (-1 - i)/sqrt 2
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const double2 *v = h ? cc : bb;
+        const double2 t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]), t2 = cadd(v[1], v[3]);
+        const double2 t3 = make_double2(v[1].y - v[3].y, -(v[1].x - v[3].x));      // -i (v1 - v3)
+        o[h + 0] = cadd(t0, t2);
+        o[h + 2] = cadd(t1, t3);
+        o[h + 4] = csub(t0, t2);
+        o[h + 6] = csub(t1, t3);
+    }
+}
+
+// 16-point DFT, natural order in and out: b_n = a_n + a_{n+8}, c_n = (a_n - a_{n+8}) W16^n, then DFT8(b) gives the even
+// and DFT8(c) the odd outputs
+__device__ __forceinline__ void dft16(const double2 (&a)[16], double2 (&o)[16]) {
+    constexpr double C1 = 0.92387953251128675613, S1 = 0.38268343236508977173, RH = 0.70710678118654752440;
+    constexpr double WR[8] = {1.0, C1, RH, S1, 0.0, -S1, -RH, -C1};
+    constexpr double WI[8] = {0.0, -S1, -RH, -C1, -1.0, -C1, -RH, -S1};
+    double2 b[8], c[8], e[8], f[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        b[n] = cadd(a[n], a[n + 8]);
+        const double2 d = csub(a[n], a[n + 8]);
+        c[n] = make_double2(d.x * WR[n] - d.y * WI[n], d.x * WI[n] + d.y * WR[n]);
+    }
+    dft8(b, e);
+    dft8(c, f);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        o[2 * m] = e[m];
+        o[2 * m + 1] = f[m];
+    }
+}
+
+// One wavefront (threadIdx.x & 63 = lane; the workgroup IS that wavefront) transforms the 1024 complex entries of buf.
+// Stockham autosort: pass A radix 16 (Ns = 1), passes B, C radix 8 (Ns = 16, 128), two butterflies per lane.
+template <bool EMIT, bool EMIT_TO_LDS, bool INGEST, class Emit, class Ingest>
+__device__ __forceinline__ void fft1024_wave(double2 *buf, const FftAxis ax, Emit emit, Ingest ingest) {
+    constexpr int LG = 10;
+    const int lane = threadIdx.x & 63;
+    {   // pass A: inputs x[lane + 64 r], outputs y[16 lane + r]
+        double2 a[16], o[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] = INGEST ? ingest(lane + 64 * r) : buf[swz<LG>(lane + 64 * r)];
+        dft16(a, o);
+        if (!INGEST) __syncthreads();             // every lane has read the image
+#pragma unroll
+        for (int r = 0; r < 16; ++r) buf[swz<LG>(16 * lane + r)] = o[r];
+        __syncthreads();
+    }
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {             // passes B (Ns = 16) and C (Ns = 128)
+        const int lNs = ps ? 7 : 4, Ns = 1 << lNs;
+        double2 o[2][8];
+        int wb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int j = lane + 64 * i, k = j & (Ns - 1);
+            double2 a[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) a[r] = buf[swz<LG>(j + 128 * r)];
+            const double2 w1 = ax.tw[k << (LG - 3 - lNs)];      // exp(-2 pi i k / (8 Ns))
+            double2 w = w1;
+            a[1] = cmul(a[1], w);
+#pragma unroll
+            for (int r = 2; r < 8; ++r) {
+                w = cmul(w, w1);
+                a[r] = cmul(a[r], w);
+            }
+            dft8(a, o[i]);
+            wb[i] = ((j >> lNs) << (lNs + 3)) + k;
+        }
+        if (EMIT && ps == 1) {
+            if (EMIT_TO_LDS) __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) emit(wb[i] + r * Ns, o[i][r]);
+            if (EMIT_TO_LDS) __syncthreads();
+        } else {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) buf[swz<LG>(wb[i] + r * Ns)] = o[i][r];
+            __syncthreads();
+        }
+    }
+}
+
 template <int C, int LOGL, class Emit = FftNoEmit, class Ingest = FftNoIngest>
 __device__ __forceinline__ void fft_lds(double2 *buf, const FftAxis ax, Emit emit = Emit(), Ingest ingest = Ingest()) {
     constexpr bool EMIT = Emit::ACTIVE && LOGL >= 9 && LOGL <= 11 && FFT_R8;
     constexpr bool INGEST = Ingest::ACTIVE && LOGL >= 9 && LOGL <= 11 && FFT_R8;
-    constexpr int T = FftThreads<C>::T;
+    constexpr int T = FftThreads<C, LOGL>::T;
     constexpr int NB4 = C / (4 * T), NB2 = C / (2 * T);
     const int tid = threadIdx.x;
     const int logL = LOGL ? LOGL : ax.logL, L = 1 << logL;
     int logNs = 0;
+#if FFT_R8 && FFT_W64
+    if constexpr (LOGL == 10 && T == 64 && C == 1024) {
+        fft1024_wave<Emit::ACTIVE != 0, Emit::TO_LDS != 0, Ingest::ACTIVE != 0>(buf, ax, emit, ingest);
+        return;
+    }
+#endif
 #if FFT_R8
     if (LOGL >= 9 && LOGL <= 11) {
         // leading radix-8 passes (Ns = 1, 8[, 64]): C/8 butterflies = one per thread (T = C/8)
-        static_assert(LOGL < 9 || LOGL > 11 || C == 8 * T, "radix-8 plan: one butterfly per thread");
+        static_assert(LOGL < 9 || LOGL > 11 || C == 8 * T || (LOGL == 10 && T == 64), "radix-8 plan: one butterfly per thread");
         constexpr int NR8 = LOGL == 10 ? 2 : 3;
         constexpr double RH = 0.70710678118654752440;
         const int f = tid >> (logL - 3), j = tid & ((L >> 3) - 1), fb = f * L;
@@ -281,15 +401,18 @@ __device__ __forceinline__ void fft_lds(double2 *buf, const FftAxis ax, Emit emi
 
 // E along the fast axis.  EPI 0: out = scale * E(in);  EPI 3: same + per-workgroup partials of
 // sum W (D[slot] - dbar) (other ? other : out) * out  into sp.gpart[b * gridDim.x + blockIdx.x] and of
-// sum W (D[slot] - dbar) out * out into sp.gpart2[same].
+// sum W (D[slot] - dbar) out * out into sp.gpart2[same];  EPI 4 (last pass of a CG sweep, see k_cg_rows_fwd):
+// out = other + scale * E(in) with the partials of sum W (D - dbar) other * out and sum W (D - dbar) out * out;
+// EPI 5 (last pass of an adjoint CG sweep, k_adj_rows_fwd): out = other + epi_c (D - dbar) scale E(in), partials with
+// the weight W / (D - dbar); there D is the plane sp.Dslot itself (d_slot_stride = 0).
 template <int EPI, int C, int LOGL>
-__global__ __launch_bounds__(FftThreads<C>::T) void k_dct_rows(Geom G, FftAxis ax, const double *__restrict__ in,
+__global__ __launch_bounds__((FftThreads<C, LOGL>::T)) void k_dct_rows(Geom G, FftAxis ax, const double *__restrict__ in,
                                                   long in_slot_stride, double *__restrict__ out, double scale,
                                                   SpecArgs sp, const TrajState *__restrict__ st, int gate) {
     const int b = blockIdx.z;
     if (gate && !gate_open(st[b], gate)) return;
     __shared__ double2 buf[FftLds<C>::SIZE];
-    constexpr int T = FftThreads<C>::T;
+    constexpr int T = FftThreads<C, LOGL>::T;
     const int tid = threadIdx.x;
     const int logL = LOGL ? LOGL : ax.logL, L = 1 << logL, N = L >> 1, nfft = C >> logL;
     const int row0 = blockIdx.x * 2 * nfft;
@@ -312,17 +435,27 @@ __global__ __launch_bounds__(FftThreads<C>::T) void k_dct_rows(Geom G, FftAxis a
     FFT_STAMP(1);
     double dot = 0.0, dot2 = 0.0, dbar = 0.0;
     const double *Dp = nullptr, *Ob = nullptr;
-    if (EPI == 3) {
+    if (EPI >= 3) {
         dbar = st[b].dbar;
         Dp = sp.Dslot + st[b].slot * sp.d_slot_stride + b * G.plane;
         Ob = sp.other ? sp.other + b * G.plane : nullptr;
     }
     double *ob = out + b * G.plane;
     auto put = [&](int row, int k, double e) {
-        const double v = scale * e;
+        double v = scale * e;
         const long o = (long)row * G.pitch + k;
+        if (EPI == 4) v += Ob[o];
+        if (EPI == 5) {
+            const double dl = Dp[o] - dbar, pv = Ob[o];
+            v = pv + sp.epi_c * dl * v;
+            ob[o] = v;
+            const double wd = wdev(row, k, G) / dl;
+            dot += wd * (pv * v);
+            dot2 += wd * (v * v);
+            return;
+        }
         ob[o] = v;
-        if (EPI == 3) {
+        if (EPI >= 3) {
             const double wd = wdev(row, k, G) * (Dp[o] - dbar);
             dot += wd * ((Ob ? Ob[o] : v) * v);
             dot2 += wd * (v * v);
@@ -375,7 +508,7 @@ __global__ __launch_bounds__(FftThreads<C>::T) void k_dct_rows(Geom G, FftAxis a
         }
     }
     FFT_STAMP(3);
-    if (EPI == 3) {
+    if (EPI >= 3) {
         dot = wave_sum(dot);
         dot2 = wave_sum(dot2);
         __syncthreads();
@@ -397,15 +530,494 @@ __global__ __launch_bounds__(FftThreads<C>::T) void k_dct_rows(Geom G, FftAxis a
     }
 }
 
+// =====================================================================================================
+// First pass of a forward CG sweep (power-of-two grids).  A = P + M Delta (Delta = D - dbar, P the constant-
+// coefficient operator the DCT inverts), so the preconditioned operator needs no stencil at all:
+//       q = P^-1 A p = p + (P^-1 M)(Delta p)
+// i.e. a point-wise multiply, the transform pair with the spectral multiplier m / P(m), and an add.  A sweep is
+//   [k_cg_rows_fwd]  resolve the reduction point of the previous sweep (every workgroup, redundantly, from the partial
+//                    sums; workgroup 0 of a trajectory records it), then on the way into the row transform
+//                    x += alpha p_old;  z' = z - alpha q;  p' = z' + beta p_old;  partial of <z',z'>_Z;  E_rows(Delta p')
+//   [k_dct_cols]     E_cols, multiplier m / P(m), E_cols
+//   [k_dct_rows<4>]  E_rows, q' = p' + (.), partials of <p',q'>_Z and <q',q'>_Z
+// three launches, 120 B per node, and the image A p' of the 13-point operator never exists.  (The GEMM-DCT path of
+// non-power-of-two grids keeps the stencil form, k_schur_p.)
+// =====================================================================================================
+struct CgSweepArgs {
+    const double *z, *q, *p_old;          // [B][plane]
+    double *x, *z_new, *p_new;
+    const double *Dslot;                  // slot-indexed D planes
+    long d_slot_stride;
+    const double *gpart, *gpart2;         // [B][gnblk] partials of <p,q>_Z, <q,q>_Z from the previous sweep's last pass
+    double *gpart3;                       // [2][B][gnblk] partials of <z',z'>_Z, copy = sweep parity
+    int it, maxit, nbatch;
+};
+
+// the three sums of a reduction point by the waves of the workgroup (fixed order); s3 = LDS [3]
+template <int T>
+__device__ __forceinline__ void cg_sums3(const double *__restrict__ g1, const double *__restrict__ g2,
+                                         const double *__restrict__ g3, int n, int b, double *s3) {
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int k = wv; k < 3; k += T / 64) {
+        const double *src = k == 0 ? g1 : (k == 1 ? g2 : g3);
+        double a = 0.0;
+        if (src)
+            for (int t = lane; t < n; t += 64) a += src[(long)b * n + t];
+        a = wave_sum(a);
+        if (lane == 0) s3[k] = a;
+    }
+    __syncthreads();
+}
+
+// The reduction point of the LAST enqueued sweep of the stencil-free form (cf. k_fin_cg_step): 192 threads.
+__global__ void k_fin_cg_step3(TrajState *st, const double *__restrict__ gpart, const double *__restrict__ gpart2,
+                               const double *__restrict__ gpart3_rd, int gnblk, int direct, int pbuf, int rd, int maxit) {
+    const int b = blockIdx.x;
+    TrajState &S = st[b];
+    __shared__ double s3[3];
+    if (!S.lin_active) return;
+    if (!S.ci_active[rd]) {                  // converged earlier: its last step is already in x
+        if (threadIdx.x == 0) { S.lin_active = 0; S.cg_pending = 0; }
+        return;
+    }
+    cg_sums3<192>(gpart, gpart2, direct ? gpart3_rd : nullptr, gnblk, b, s3);
+    if (threadIdx.x != 0) return;
+    const CgNext n = cg_next(s3[0], s3[1], direct ? s3[2] : S.ci_gamma[rd], S.cg_gamma0, S.ci_it[rd], S.lin_reltol, maxit);
+    cg_record(S, n, rd ^ 1);
+    S.cg_pending = n.breakdown ? 0 : 1;
+    S.cg_pbuf = pbuf;
+    S.lin_active = n.active;
+}
+
+template <int FIRST, int C, int LOGL>
+__global__ __launch_bounds__((FftThreads<C, LOGL>::T)) void k_cg_rows_fwd(Geom G, FftAxis ax, CgSweepArgs a, double *__restrict__ out,
+                                                                         TrajState *__restrict__ st) {
+    const int b = blockIdx.z;
+    __shared__ double2 buf[FftLds<C>::SIZE];
+    __shared__ double s3[4];
+    constexpr int T = FftThreads<C, LOGL>::T;
+    const int tid = threadIdx.x;
+    const int logL = LOGL ? LOGL : ax.logL, L = 1 << logL, N = L >> 1, nfft = C >> logL;
+    const int row0 = blockIdx.x * 2 * nfft, n1 = N + 1;
+    const int rd = (a.it + 1) & 1, wr = a.it & 1;
+    const long pb = b * G.plane;
+    double alpha = 0.0, beta = 0.0;
+    if (FIRST) {
+        if (!st[b].ci_active[0]) return;
+    } else {
+        if (!st[b].ci_active[rd]) {
+            if (blockIdx.x == 0 && tid == 0) {             // hand the (finished) state on to the other copy
+                st[b].ci_active[wr] = 0;
+                st[b].ci_it[wr] = st[b].ci_it[rd];
+                st[b].ci_gamma[wr] = st[b].ci_gamma[rd];
+            }
+            return;
+        }
+        const double gamma0 = st[b].cg_gamma0, gamma_old = st[b].ci_gamma[rd], tol = st[b].lin_reltol;
+        const int it_old = st[b].ci_it[rd], n = gridDim.x;
+        cg_sums3<T>(a.gpart, a.gpart2, a.it >= 2 ? a.gpart3 + (long)rd * a.nbatch * n : nullptr, n, b, s3);
+        const CgNext nx = cg_next(s3[0], s3[1], a.it >= 2 ? s3[2] : gamma_old, gamma0, it_old, tol, a.maxit);
+        if (blockIdx.x == 0 && tid == 0) cg_record(st[b], nx, wr);
+        alpha = nx.alpha;
+        beta = nx.beta;
+        if (!nx.active) {                                  // converged (or broke down, alpha = 0): take the step only
+            if (!nx.breakdown)
+                for (int idx = tid; idx < 2 * nfft * n1; idx += T) {
+                    const int rr = idx / n1, k = idx - rr * n1, row = row0 + rr;
+                    if (row < G.ns) {
+                        const long o = pb + (long)row * G.pitch + k;
+                        a.x[o] += alpha * a.p_old[o];
+                    }
+                }
+            return;
+        }
+    }
+    const double dbar = st[b].dbar;
+    const double *Dp = a.Dslot + st[b].slot * a.d_slot_stride + pb;
+    double acc = 0.0;
+    // value fed into the transform at node (row, m); the OWNER visit (each node exactly once) also applies the step
+    auto node = [&](int row, int m, bool owner) -> double {
+        if (row >= G.ns) return 0.0;
+        const long o = (long)row * G.pitch + m;
+        const double dl = Dp[o] - dbar;
+        double pn;
+        if (FIRST) {
+            pn = a.z[pb + o];
+            if (owner) {
+                a.x[pb + o] = 0.0;
+                a.p_new[pb + o] = pn;
+            }
+        } else {
+            const double po = a.p_old[pb + o];
+            const double zn = a.z[pb + o] - alpha * a.q[pb + o];
+            pn = zn + beta * po;
+            if (owner) {
+                a.x[pb + o] += alpha * po;
+                a.z_new[pb + o] = zn;
+                a.p_new[pb + o] = pn;
+                acc += wdev(row, m, G) * dl * (zn * zn);
+            }
+        }
+        return dl * pn;
+    };
+    double *ob = out + pb;
+    auto put = [&](int row, int k, double e) { ob[(long)row * G.pitch + k] = e; };
+    constexpr bool DIRECT = FFT_R8 && LOGL >= 9 && LOGL <= 11;
+    if (DIRECT) {
+        struct Emit {
+            enum { ACTIVE = 1, TO_LDS = 0 };
+            decltype(put) &put_;
+            int row0_, ns_;
+            __device__ __forceinline__ void operator()(int idx, double2 v) const {
+                constexpr int LL = 1 << (LOGL ? LOGL : 1);
+                const int f = idx >> (LOGL ? LOGL : 1), k = idx & (LL - 1);
+                if (k <= LL / 2) {
+                    const int ra = row0_ + 2 * f;
+                    if (ra < ns_) put_(ra, k, v.x);
+                    if (ra + 1 < ns_) put_(ra + 1, k, v.y);
+                }
+            }
+        };
+        struct Ingest {
+            enum { ACTIVE = 1 };
+            decltype(node) &node_;
+            int row0_;
+            __device__ __forceinline__ double2 operator()(int idx) const {
+                constexpr int LL = 1 << (LOGL ? LOGL : 1);
+                const int f = idx >> (LOGL ? LOGL : 1), i = idx & (LL - 1);
+                const bool owner = i <= LL / 2;
+                const int m = owner ? i : LL - i, ra = row0_ + 2 * f;
+                return make_double2(node_(ra, m, owner), node_(ra + 1, m, owner));
+            }
+        };
+        fft_lds<C, LOGL>(buf, ax, Emit{put, row0, G.ns}, Ingest{node, row0});
+    } else {
+        const float inv_n1 = 1.0f / (float)n1;
+        for (int idx = tid; idx < nfft * n1; idx += T) {
+            const int f = nfft == 1 ? 0 : (int)(((float)idx + 0.5f) * inv_n1), j = idx - f * n1;
+            const int ra = row0 + 2 * f;
+            const double2 v = make_double2(node(ra, j, true), node(ra + 1, j, true));
+            buf[swz<LOGL>(f * L + j)] = v;
+            if (j > 0 && j < N) buf[swz<LOGL>(f * L + L - j)] = v;
+        }
+        __syncthreads();
+        fft_lds<C, LOGL>(buf, ax);
+        for (int idx = tid; idx < 2 * nfft * n1; idx += T) {
+            const int rr = nfft == 1 ? (idx >= n1 ? 1 : 0) : (int)(((float)idx + 0.5f) * inv_n1), k = idx - rr * n1;
+            const int row = row0 + rr;
+            if (row < G.ns) {
+                const double2 c = buf[swz<LOGL>((rr >> 1) * L + k)];
+                put(row, k, (rr & 1) ? c.y : c.x);
+            }
+        }
+    }
+    if (!FIRST) {
+        acc = wave_sum(acc);
+        __syncthreads();
+        double *sred = reinterpret_cast<double *>(buf);
+        if ((tid & 63) == 0) sred[tid >> 6] = acc;
+        __syncthreads();
+        if (tid == 0) {
+            double tot = 0.0;
+            for (int w = 0; w < T / 64; ++w) tot += sred[w];
+            a.gpart3[((long)wr * a.nbatch + b) * gridDim.x + blockIdx.x] = tot;
+        }
+    }
+}
+
+// =====================================================================================================
+// Adjoint CG sweep in the same stencil-free form.  A(phi_n) = P + c Delta M (c = dt/2, Delta = D_n - dbar,
+// P = I + (tau + c dbar) M + c M^2), right preconditioning: with x = x0 + P^-1 y the operator on y is
+//       A P^-1 = I + c Delta (M P^-1),
+// self-adjoint and positive in <a,b>_Z' = sum W a b / Delta.  CG on y with ONE reduction point per sweep:
+//   [k_adj_rows_fwd]  resolve the previous sweep's reduction point (alpha = gamma / <ph,q>, predicted
+//                     gamma' = alpha^2 <q,q> - gamma, beta = gamma'/gamma, stop test), then on the way into the row
+//                     transform  y += alpha ph_old;  r' = r - alpha q;  ph' = r' + beta ph_old;  partials of
+//                     <r',r'>_Z' and ||r'||_2^2;  E_rows(ph')
+//   [k_dct_cols]      E_cols, multiplier m / P(m), E_cols
+//   [k_dct_rows<5>]   E_rows, q' = ph' + c Delta (.), partials of <ph',q'>_Z' and <q',q'>_Z'
+// and after the last sweep x = x0 + P^-1 y (one more transform pair, k_dct_rows<4> adds x0).  The stop test is the
+// reference's accuracy class, ||r||_2 <= tol ||rhs||_2, evaluated as the last directly summed ||r||_2 times the
+// predicted decrease of the Z' norm.
+// =====================================================================================================
+struct AdjSweepArgs {
+    const double *r, *q, *p_old;          // [B][plane]
+    double *y, *r_new, *p_new;
+    const double *Dn;                     // f''(phi_n) plane
+    const double *gpart, *gpart2;         // [B][gnblk] partials of <ph,q>_Z', <q,q>_Z' of the previous sweep
+    double *gpart3;                       // [2][B][gnblk][2] partials of <r',r'>_Z' and ||r'||^2, copy = sweep parity
+    int it, maxit, nbatch;
+};
+
+struct CgNextAdj {
+    int active, breakdown, it;
+    double alpha, beta, gamma, rel;
+};
+__device__ __forceinline__ CgNextAdj cg_next_adj(double pq, double qq, double gamma, double r2, double rhs_norm, int it_old,
+                                                 double tol, int maxit) {
+    CgNextAdj n;
+    n.it = it_old;
+    const double rel_now = rhs_norm > 0.0 ? sqrt(fmax(r2, 0.0)) / rhs_norm : 0.0;
+    if (!(pq > 0.0) || !(gamma > 0.0)) {     // round-off level residual: stop here, no step
+        n.active = 0; n.breakdown = 1; n.alpha = 0.0; n.beta = 0.0; n.gamma = fmax(gamma, 0.0); n.rel = rel_now;
+        return n;
+    }
+    n.breakdown = 0;
+    n.alpha = gamma / pq;
+    double gn = n.alpha * n.alpha * qq - gamma;
+    if (gn > 1e-13 * gamma) {
+        n.beta = gn / gamma;
+    } else {                                  // prediction lost in cancellation: restart the direction
+        gn = 1e-13 * gamma;
+        n.beta = 0.0;
+    }
+    n.gamma = gn;
+    n.it = it_old + 1;
+    n.rel = sqrt(gn / gamma) * rel_now;
+    n.active = (n.rel > tol && n.it < maxit) ? 1 : 0;
+    return n;
+}
+__device__ __forceinline__ void adj_record(TrajState &S, const CgNextAdj &n, int wr) {
+    S.cg_alpha = n.alpha;
+    S.cg_beta = n.beta;
+    S.cg_gamma = n.gamma;
+    S.lin_rel = n.rel;
+    if (!n.breakdown) {
+        S.lin_it = n.it;
+        S.lin_total++;
+    }
+    if (!n.active && n.rel > S.lin_maxrel) S.lin_maxrel = n.rel;
+    S.ci_active[wr] = n.active;
+    S.ci_it[wr] = n.it;
+    S.ci_gamma[wr] = n.gamma;
+}
+
+// the four sums of an adjoint reduction point (fixed order); g3 holds pairs {Z' norm^2, 2-norm^2}; s4 = LDS [4]
+template <int T>
+__device__ __forceinline__ void adj_sums4(const double *__restrict__ g1, const double *__restrict__ g2,
+                                          const double *__restrict__ g3, int n, int b, double *s4) {
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int k = wv; k < 4; k += T / 64) {
+        double a = 0.0;
+        if (k < 2) {
+            const double *src = k == 0 ? g1 : g2;
+            for (int t = lane; t < n; t += 64) a += src[(long)b * n + t];
+        } else if (g3) {
+            for (int t = lane; t < n; t += 64) a += g3[((long)b * n + t) * 2 + (k - 2)];
+        }
+        a = wave_sum(a);
+        if (lane == 0) s4[k] = a;
+    }
+    __syncthreads();
+}
+
+// Start of an adjoint solve, after k_adj_op<1> (r0 = rhs - A x0 with the partials {<r0,r0>_Z', ||r0||^2} in the
+// stencil-tile layout `part`): gamma0, the 2-norm of r0 and the per-sweep state copies.
+__global__ void k_fin_adj_init(TrajState *st, const double *__restrict__ part, int nblk, double tol, int maxit) {
+    const int b = blockIdx.x;
+    TrajState &S = st[b];
+    if (threadIdx.x == 0) {
+        S.cg_pending = 0;
+        if (!S.lin_active) S.ci_active[0] = S.lin_took = 0;
+    }
+    if (!S.lin_active) return;
+    const double g = fin_sum1(part, nblk, b, NPART, 0), r2 = fin_sum1(part, nblk, b, NPART, 1);
+    if (threadIdx.x != 0) return;
+    S.cg_gamma = S.cg_gamma0 = g;
+    S.cg_beta = 0.0;
+    S.lin_it = 0;
+    S.lin_reltol = tol;
+    S.aux[0] = r2;                                        // ||r0||^2, the 2-norm the first reduction point scales
+    S.lin_rel = S.lin_r0 > 0.0 ? sqrt(r2) / S.lin_r0 : 0.0;
+    if (!(S.lin_rel > tol) || !(g > 0.0)) {               // the initial guess already solves the system
+        S.lin_active = 0;
+        if (S.lin_rel > S.lin_maxrel) S.lin_maxrel = S.lin_rel;
+    }
+    S.ci_active[0] = S.lin_active;
+    S.lin_took = S.lin_active;
+    S.ci_it[0] = 0;
+    S.ci_gamma[0] = g;
+}
+
+// The reduction point of the LAST enqueued adjoint sweep; leaves the step pending for k_cg_finish (on y).
+__global__ void k_fin_adj_step(TrajState *st, const double *__restrict__ gpart, const double *__restrict__ gpart2,
+                               const double *__restrict__ gpart3_rd, int gnblk, int direct, int pbuf, int rd, int maxit) {
+    const int b = blockIdx.x;
+    TrajState &S = st[b];
+    __shared__ double s4[4];
+    if (!S.lin_active) return;
+    if (!S.ci_active[rd]) {
+        if (threadIdx.x == 0) { S.lin_active = 0; S.cg_pending = 0; }
+        return;
+    }
+    adj_sums4<192>(gpart, gpart2, direct ? gpart3_rd : nullptr, gnblk, b, s4);
+    if (threadIdx.x != 0) return;
+    const CgNextAdj n = cg_next_adj(s4[0], s4[1], direct ? s4[2] : S.ci_gamma[rd], direct ? s4[3] : S.aux[0], S.lin_r0,
+                                    S.ci_it[rd], S.lin_reltol, maxit);
+    adj_record(S, n, rd ^ 1);
+    if (n.it > S.step_lin_max) S.step_lin_max = n.it;
+    S.cg_pending = n.breakdown ? 0 : 1;
+    S.cg_pbuf = pbuf;
+    S.lin_active = n.active;      // still set: the enqueued sweeps did not reach the tolerance (k_fin_lin_begin counts it)
+}
+
+template <int FIRST, int C, int LOGL>
+__global__ __launch_bounds__((FftThreads<C, LOGL>::T)) void k_adj_rows_fwd(Geom G, FftAxis ax, AdjSweepArgs a, double *__restrict__ out,
+                                                                          TrajState *__restrict__ st) {
+    const int b = blockIdx.z;
+    __shared__ double2 buf[FftLds<C>::SIZE];
+    __shared__ double s4[4];
+    constexpr int T = FftThreads<C, LOGL>::T;
+    const int tid = threadIdx.x;
+    const int logL = LOGL ? LOGL : ax.logL, L = 1 << logL, N = L >> 1, nfft = C >> logL;
+    const int row0 = blockIdx.x * 2 * nfft, n1 = N + 1;
+    const int rd = (a.it + 1) & 1, wr = a.it & 1;
+    const long pb = b * G.plane;
+    double alpha = 0.0, beta = 0.0;
+    if (FIRST) {
+        if (!st[b].ci_active[0]) return;
+    } else {
+        if (!st[b].ci_active[rd]) {
+            if (blockIdx.x == 0 && tid == 0) {
+                st[b].ci_active[wr] = 0;
+                st[b].ci_it[wr] = st[b].ci_it[rd];
+                st[b].ci_gamma[wr] = st[b].ci_gamma[rd];
+            }
+            return;
+        }
+        const double gamma_old = st[b].ci_gamma[rd], tol = st[b].lin_reltol, r0sq = st[b].aux[0], rhsn = st[b].lin_r0;
+        const int it_old = st[b].ci_it[rd], n = gridDim.x;
+        adj_sums4<T>(a.gpart, a.gpart2, a.it >= 2 ? a.gpart3 + (long)rd * a.nbatch * n * 2 : nullptr, n, b, s4);
+        const CgNextAdj nx = cg_next_adj(s4[0], s4[1], a.it >= 2 ? s4[2] : gamma_old, a.it >= 2 ? s4[3] : r0sq, rhsn, it_old, tol,
+                                         a.maxit);
+        if (blockIdx.x == 0 && tid == 0) {
+            adj_record(st[b], nx, wr);
+            if (nx.it > st[b].step_lin_max) st[b].step_lin_max = nx.it;
+        }
+        alpha = nx.alpha;
+        beta = nx.beta;
+        if (!nx.active) {
+            if (!nx.breakdown)
+                for (int idx = tid; idx < 2 * nfft * n1; idx += T) {
+                    const int rr = idx / n1, k = idx - rr * n1, row = row0 + rr;
+                    if (row < G.ns) {
+                        const long o = pb + (long)row * G.pitch + k;
+                        a.y[o] += alpha * a.p_old[o];
+                    }
+                }
+            return;
+        }
+    }
+    const double dbar = st[b].dbar;
+    const double *Dp = a.Dn + pb;
+    double acc = 0.0, acc2 = 0.0;
+    auto node = [&](int row, int m, bool owner) -> double {
+        if (row >= G.ns) return 0.0;
+        const long o = pb + (long)row * G.pitch + m;
+        double pn;
+        if (FIRST) {
+            pn = a.r[o];
+            if (owner) {
+                a.y[o] = 0.0;
+                a.p_new[o] = pn;
+            }
+        } else {
+            const double po = a.p_old[o];
+            const double rn = a.r[o] - alpha * a.q[o];
+            pn = rn + beta * po;
+            if (owner) {
+                a.y[o] += alpha * po;
+                a.r_new[o] = rn;
+                a.p_new[o] = pn;
+                acc += wdev(row, m, G) / (Dp[o - pb] - dbar) * (rn * rn);
+                acc2 += rn * rn;
+            }
+        }
+        return pn;
+    };
+    double *ob = out + pb;
+    auto put = [&](int row, int k, double e) { ob[(long)row * G.pitch + k] = e; };
+    constexpr bool DIRECT = FFT_R8 && LOGL >= 9 && LOGL <= 11;
+    if (DIRECT) {
+        struct Emit {
+            enum { ACTIVE = 1, TO_LDS = 0 };
+            decltype(put) &put_;
+            int row0_, ns_;
+            __device__ __forceinline__ void operator()(int idx, double2 v) const {
+                constexpr int LL = 1 << (LOGL ? LOGL : 1);
+                const int f = idx >> (LOGL ? LOGL : 1), k = idx & (LL - 1);
+                if (k <= LL / 2) {
+                    const int ra = row0_ + 2 * f;
+                    if (ra < ns_) put_(ra, k, v.x);
+                    if (ra + 1 < ns_) put_(ra + 1, k, v.y);
+                }
+            }
+        };
+        struct Ingest {
+            enum { ACTIVE = 1 };
+            decltype(node) &node_;
+            int row0_;
+            __device__ __forceinline__ double2 operator()(int idx) const {
+                constexpr int LL = 1 << (LOGL ? LOGL : 1);
+                const int f = idx >> (LOGL ? LOGL : 1), i = idx & (LL - 1);
+                const bool owner = i <= LL / 2;
+                const int m = owner ? i : LL - i, ra = row0_ + 2 * f;
+                return make_double2(node_(ra, m, owner), node_(ra + 1, m, owner));
+            }
+        };
+        fft_lds<C, LOGL>(buf, ax, Emit{put, row0, G.ns}, Ingest{node, row0});
+    } else {
+        const float inv_n1 = 1.0f / (float)n1;
+        for (int idx = tid; idx < nfft * n1; idx += T) {
+            const int f = nfft == 1 ? 0 : (int)(((float)idx + 0.5f) * inv_n1), j = idx - f * n1;
+            const int ra = row0 + 2 * f;
+            const double2 v = make_double2(node(ra, j, true), node(ra + 1, j, true));
+            buf[swz<LOGL>(f * L + j)] = v;
+            if (j > 0 && j < N) buf[swz<LOGL>(f * L + L - j)] = v;
+        }
+        __syncthreads();
+        fft_lds<C, LOGL>(buf, ax);
+        for (int idx = tid; idx < 2 * nfft * n1; idx += T) {
+            const int rr = nfft == 1 ? (idx >= n1 ? 1 : 0) : (int)(((float)idx + 0.5f) * inv_n1), k = idx - rr * n1;
+            const int row = row0 + rr;
+            if (row < G.ns) {
+                const double2 c = buf[swz<LOGL>((rr >> 1) * L + k)];
+                put(row, k, (rr & 1) ? c.y : c.x);
+            }
+        }
+    }
+    if (!FIRST) {
+        acc = wave_sum(acc);
+        acc2 = wave_sum(acc2);
+        __syncthreads();
+        double *sred = reinterpret_cast<double *>(buf);
+        if ((tid & 63) == 0) {
+            sred[tid >> 6] = acc;
+            sred[T / 64 + (tid >> 6)] = acc2;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double tot = 0.0, tot2 = 0.0;
+            for (int w = 0; w < T / 64; ++w) {
+                tot += sred[w];
+                tot2 += sred[T / 64 + w];
+            }
+            double *dst = a.gpart3 + (((long)wr * a.nbatch + b) * gridDim.x + blockIdx.x) * 2;
+            dst[0] = tot;
+            dst[1] = tot2;
+        }
+    }
+}
+
 // E along the slow axis, spectral multiplier 1/(c0 + m (c1 + c2 m)) (m = ms[k] + mf[col]), E again.
 template <int C, int LOGL>
-__global__ __launch_bounds__(FftThreads<C>::T) void k_dct_cols(Geom G, FftAxis ax, const double *__restrict__ in,
+__global__ __launch_bounds__((FftThreads<C, LOGL>::T)) void k_dct_cols(Geom G, FftAxis ax, const double *__restrict__ in,
                                                   double *__restrict__ out, double scale, SpecArgs sp,
                                                   const TrajState *__restrict__ st, int gate) {
     const int b = blockIdx.z;
     if (gate && !gate_open(st[b], gate)) return;
     __shared__ double2 buf[FftLds<C>::SIZE];
-    constexpr int T = FftThreads<C>::T;
+    constexpr int T = FftThreads<C, LOGL>::T;
     const int tid = threadIdx.x;
     const int logL = LOGL ? LOGL : ax.logL, L = 1 << logL, N = L >> 1, nfft = C >> logL, ncol = 2 * nfft;
     const int col0 = xcd_remap(blockIdx.x, gridDim.x) * ncol;
@@ -455,8 +1067,8 @@ __global__ __launch_bounds__(FftThreads<C>::T) void k_dct_cols(Geom G, FftAxis a
             const int ca = col0_ + 2 * f, cb = ca + 1;
             const double msk = sp_.ms[ks];
             const double ma = msk + sp_.mf[ca < nf_ ? ca : nf_ - 1], mb = msk + sp_.mf[cb < nf_ ? cb : nf_ - 1];
-            v.x *= scale_ / (sp_.c0 + ma * (c1_ + sp_.c2 * ma));
-            v.y *= scale_ / (sp_.c0 + mb * (c1_ + sp_.c2 * mb));
+            v.x *= scale_ * (sp_.mult_m ? ma : 1.0) / (sp_.c0 + ma * (c1_ + sp_.c2 * ma));
+            v.y *= scale_ * (sp_.mult_m ? mb : 1.0) / (sp_.c0 + mb * (c1_ + sp_.c2 * mb));
             buf_[swz<LOGL>(idx)] = v;
         }
     };
@@ -474,8 +1086,8 @@ __global__ __launch_bounds__(FftThreads<C>::T) void k_dct_cols(Geom G, FftAxis a
             const double msk = sp.ms[ks];
             double2 v = buf[swz<LOGL>(idx)];
             double ma = msk + sp.mf[ca < G.nf ? ca : G.nf - 1], mb = msk + sp.mf[cb < G.nf ? cb : G.nf - 1];
-            v.x *= scale / (sp.c0 + ma * (c1 + sp.c2 * ma));
-            v.y *= scale / (sp.c0 + mb * (c1 + sp.c2 * mb));
+            v.x *= scale * (sp.mult_m ? ma : 1.0) / (sp.c0 + ma * (c1 + sp.c2 * ma));
+            v.y *= scale * (sp.mult_m ? mb : 1.0) / (sp.c0 + mb * (c1 + sp.c2 * mb));
             buf[swz<LOGL>(idx)] = v;
         }
         __syncthreads();

@@ -36,6 +36,8 @@ struct SpecArgs {           // multiplier = 1 / (c0 + m (c1a + c1b*dbar[b] + c2 
     long d_slot_stride;
     double *gpart;           // [B][gridDim.x*gridDim.y]
     double *gpart2;          // same layout: partial of sum W (D - dbar) C * C
+    int mult_m;              // FFT column pass: multiplier m / (c0 + ...) instead of 1 / (c0 + ...)
+    double epi_c;            // EPI 5 (adjoint sweep): out = other + epi_c (D - dbar) E(in)
 };
 
 // EPI: 0 store, 1 store * spectral multiplier, 2 accumulate (C += A B), 3 store + weighted dot partial

@@ -46,6 +46,7 @@ struct TrajState {
     // per time step, for the host's launch schedule: linear solves started and the longest of them
     int step_solves, step_lin_max;
     int step_lin[4];           // sweeps of the first four solves of the step
+    int lin_took, lin_unconv;  // adjoint: this solve started (its y is valid); solves the enqueued sweeps did not finish
     int cg_pending, cg_pbuf, cg_pad;   // forward CG: step (alpha, p[cg_pbuf]) computed but not yet added to x
     // forward CG, per-iteration state in two copies: iteration k's stencil kernel derives the step of
     // iteration k-1 itself (every workgroup, redundantly), reading copy (k-1)&1 while one workgroup
@@ -59,8 +60,9 @@ struct TrajState {
 };
 
 // gate codes of the preconditioner kernels: 1 = lin_active, 2 / 3 = copy 0 / 1 of the forward CG's per-iteration flag
+// 4 = the adjoint solve of this step took place (lin_took)
 __device__ __forceinline__ bool gate_open(const TrajState &S, int gate) {
-    return gate == 1 ? S.lin_active != 0 : S.ci_active[gate - 2] != 0;
+    return gate == 1 ? S.lin_active != 0 : (gate == 4 ? S.lin_took != 0 : S.ci_active[gate - 2] != 0);
 }
 
 struct Phys {
@@ -1190,6 +1192,10 @@ __global__ void k_fin_lin_begin(TrajState *st, const double *__restrict__ part, 
                                 double tau, double kappa, double dt, double lin_tol) {
     const int b = blockIdx.x;
     TrajState &S = st[b];
+    if (threadIdx.x == 0 && S.lin_active) {      // the previous solve of this trajectory ended on its sweep budget
+        S.lin_unconv++;
+        if (S.lin_rel > S.lin_maxrel) S.lin_maxrel = S.lin_rel;
+    }
     double v[NPART];
     const int op0[NPART] = {1, 2, 0, 0, 0, 0};
     const int op1[NPART] = {0, 0, 0, 0, 0, 0};
