@@ -12,9 +12,16 @@ import csv, glob, json, sys, collections
 out = sys.argv[1]
 N, B, M = 512, 8, 40
 nodes = (N + 1) * (N + 1) * B
-alg = {"k_schur_p<0>": (40, 32), "k_schur_p<1>": (16, 16), "k_residual<1>": (48, 40), "k_dct_rows<0, 1024, 10>": (8, 8),
-       "k_dct_rows<3, 1024, 10>": (24, 8), "k_dct_cols<1024, 10>": (8, 8), "k_adj_q": (24, 8), "k_cg_update_adj": (32, 16),
-       "k_grad_prox": (16, 8), "k_cost": (24, 0)}
+# (read, write) algorithmic bytes per node per dispatch; third entry: which read calibration applies
+#   "stream": 8 B/lane coalesced streaming reads (row FFT ingest, element-wise kernels), calibrated on k_grad_prox
+#   "tile":   8 B/lane reads of 64 x 16 tiles (the stencil kernels), calibrated on k_copy_plane (a pure tiled copy)
+alg = {"k_cg_rows_fwd<0, 1024, 10>": (40, 32, "stream"), "k_cg_rows_fwd<1, 1024, 10>": (16, 24, "stream"),
+       "k_dct_rows<0, 1024, 10>": (8, 8, "stream"), "k_dct_rows<3, 1024, 10>": (16, 8, "stream"),
+       "k_dct_rows<4, 1024, 10>": (24, 8, "stream"), "k_dct_rows<5, 1024, 10>": (24, 8, "stream"),
+       "k_dct_cols<1024, 10>": (8, 8, "stream"), "k_adj_rows_fwd<0, 1024, 10>": (40, 32, "stream"),
+       "k_residual<1>": (48, 40, "tile"), "k_residual<0>": (32, 32, "tile"), "k_prepare": (40, 32, "tile"),
+       "k_dmu_ceiling": (32, 8, "tile"), "k_adj_rhs": (48, 16, "tile"), "k_schur_p<0>": (40, 32, "tile"),
+       "k_copy_plane": (8, 8, "tile"), "k_grad_prox": (16, 8, "stream"), "k_cost": (24, 0, "stream")}
 res = {}
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     files = glob.glob(f"{out}/{ctr}/*/*counter_collection.csv")
@@ -33,17 +40,21 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         res.setdefault(k, {})[ctr] = dict(dispatches=len(v), live=len(live), mean_bytes=sum(live) / max(len(live), 1))
 summary = {}
 levels = M + 1
-cal = None
+cal = {"stream": None, "tile": None}
 if "k_grad_prox" in res and "FETCH_SIZE" in res["k_grad_prox"]:
-    known = 16.0 * nodes * levels
-    cal = res["k_grad_prox"]["FETCH_SIZE"]["mean_bytes"] / known
+    cal["stream"] = res["k_grad_prox"]["FETCH_SIZE"]["mean_bytes"] / (16.0 * nodes * levels)
+if "k_copy_plane" in res and "FETCH_SIZE" in res["k_copy_plane"]:
+    cal["tile"] = res["k_copy_plane"]["FETCH_SIZE"]["mean_bytes"] / (8.0 * nodes)
 for k, d in res.items():
-    rd, wr = alg[k]
+    rd, wr, kind = alg[k]
     mult = levels if k in ("k_grad_prox", "k_cost") else 1
     f = d.get("FETCH_SIZE", {}).get("mean_bytes")
     w = d.get("WRITE_SIZE", {}).get("mean_bytes")
+    c = cal[kind] or cal["stream"]
     summary[k] = dict(algorithmic_read=rd * nodes * mult, algorithmic_write=wr * nodes * mult,
-                      fetch_raw=f, write_raw=w,
-                      fetch_corrected=(f / cal if (f is not None and cal) else None),
+                      fetch_raw=f, write_raw=w, read_calibration=kind,
+                      fetch_corrected=(f / c if (f is not None and c) else None),
+                      traffic_over_algorithmic=(((f / c if c else f) + w) / ((rd + wr) * nodes * mult)
+                                                if (f is not None and w is not None) else None),
                       dispatches=d.get("FETCH_SIZE", d.get("WRITE_SIZE"))["dispatches"])
-print(json.dumps(dict(calibration_fetch_ratio_8B_per_lane=cal, kernels=summary), indent=1))
+print(json.dumps(dict(trajectories_per_launch=B, grid=N, calibration_fetch_ratio=cal, kernels=summary), indent=1))

@@ -11,5 +11,6 @@ for CTR in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 400 rocprofv3 --pmc $CTR --kernel-trace --output-format csv -d $OUT/$CTR -- python bench.py $ARGS > $OUT/$CTR.json 2> $OUT/$CTR.err
 done
 python scripts/pmc_summarise.py $OUT > $OUT/summary.json
+cp $OUT/summary.json gpurun_out/r2_pmc_traffic.json
 cat $OUT/summary.json
 find $OUT -name "*.csv" -size +20M -delete

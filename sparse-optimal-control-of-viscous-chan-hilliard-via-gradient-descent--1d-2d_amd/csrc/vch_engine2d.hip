@@ -52,6 +52,7 @@ struct vch2d_ctx {
     // DCT-I matrices and eigenvalues
     double *Q1f, *Q2f, *Q1s, *Q2s, *mf, *ms;
     bool use_fft;                         // both axes power-of-two: in-LDS FFT instead of the GEMMs
+    int cols_c;                           // complex image per workgroup of the column pass at 1024-point length (columns = 2 C / 1024)
     FftAxis fax, sax;
     FftAxis fax_h, sax_h;                 // half-length plans (FFT length N) of the half-size DCT-I, N = 512 only
     double2 *tw_fh = nullptr, *tw_sh = nullptr;
@@ -256,6 +257,8 @@ extern "C" vch2d_ctx *vch2d_create(const vch2d_params *p, int batch, int max_ste
     // (newton_lin_tol in vch_kernels2d.h); 0 = always lin_tol
     c->lin_eta = 0.05 * NEWTON_TOL;
     if (const char *e = getenv("VCH_LIN_ETA")) c->lin_eta = atof(e);
+    c->cols_c = 1024;          // 2048 equal, 4096 slower (profiles/r02_cols_width.txt)
+    if (const char *e = getenv("VCH_COLS_C")) c->cols_c = atoi(e);
     c->spec = getenv("VCH_NO_SPEC") == nullptr;
     c->spec_slots = 2;
     for (int &n : c->spec_cgb) n = 12;
@@ -433,6 +436,14 @@ static int precond(vch2d_ctx *c, const double *in, long in_slot_stride, double *
         LAUNCHC(PC_DCT_C, (k_dct_cols<C_, LG_>), dim3((nf + cpw - 1) / cpw, 1, c->B), dim3(FftThreads<C_, LG_>::T), G, \
                 c->sax, (const double *)c->t1, c->t2, scale, sp, c->st, gate);                                  \
     } while (0)
+        // the column pass reads 16 bytes per row and column pair: a workgroup that owns 2 C / 1024 adjacent columns uses
+        // that share of every 128-byte line it pulls through L2 (profiles/r02_cols_width.txt)
+#define DCT_COLS_10()                                        \
+    do {                                                     \
+        if (c->cols_c == 4096) DCT_COLS(4096, 10);           \
+        else if (c->cols_c == 2048) DCT_COLS(2048, 10);      \
+        else DCT_COLS(1024, 10);                             \
+    } while (0)
         // FFT lengths 512 / 1024 / 2048 (grids 256^2, 512^2, 1024^2) are compiled with a constant length
 #define DCT_ROWS_ANY(EPI_, in_, iss_, out_)                                       \
     do {                                                                          \
@@ -450,7 +461,7 @@ static int precond(vch2d_ctx *c, const double *in, long in_slot_stride, double *
         if (c->half_s)
             LAUNCHC(PC_DCT_C, k_dcth_cols, dim3((nf + 3) / 4, 1, c->B), dim3(HT), G, c->sax, c->sax_h, (const double *)c->t1, c->t2,
                     scale, sp, c->st, gate);
-        else if (c->sax.logL == 10) DCT_COLS(1024, 10);
+        else if (c->sax.logL == 10) DCT_COLS_10();
         else if (c->sax.logL == 9) DCT_COLS(1024, 9);
         else if (c->sax.logL < 10) DCT_COLS(1024, 0);
         else if (c->sax.logL == 11) DCT_COLS(2048, 11);
@@ -489,7 +500,7 @@ static int sweep_tail(vch2d_ctx *c, const double *p, double *q, double c0, doubl
     const int ns = G.ns, nf = G.nf;
     SpecArgs sp{c0, 0.0, 1.0, c2, c->ms, c->mf, p, c->D_s, c->slot_stride, c->gpart, c->gpart2, 1};
     const double scale = 1.0 / (4.0 * (double)c->fax.N * (double)c->sax.N);
-    if (c->sax.logL == 10) DCT_COLS(1024, 10);
+    if (c->sax.logL == 10) DCT_COLS_10();
     else if (c->sax.logL == 9) DCT_COLS(1024, 9);
     else if (c->sax.logL < 10) DCT_COLS(1024, 0);
     else if (c->sax.logL == 11) DCT_COLS(2048, 11);
@@ -880,7 +891,7 @@ static int adjoint_solve_cg(vch2d_ctx *c, double dt, int budget, bool look) {
                 SpecArgs sp{1.0, c->P.tau, cadj, cadj, c->ms, c->mf, pn, c->cmu, 0L, c->gpart, c->gpart2, 1, cadj};
                 const double scale = 1.0 / (4.0 * (double)c->fax.N * (double)c->sax.N);
                 const int gate = 2 + (done & 1);
-                if (c->sax.logL == 10) DCT_COLS(1024, 10);
+                if (c->sax.logL == 10) DCT_COLS_10();
                 else if (c->sax.logL == 9) DCT_COLS(1024, 9);
                 else if (c->sax.logL < 10) DCT_COLS(1024, 0);
                 else if (c->sax.logL == 11) DCT_COLS(2048, 11);
