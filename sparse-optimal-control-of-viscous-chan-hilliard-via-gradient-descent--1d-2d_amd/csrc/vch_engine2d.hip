@@ -39,6 +39,8 @@ struct vch2d_ctx {
     double *w, *wnew, *mu0, *cphi, *cmu, *x, *r, *dmu, *t1, *t2;
     double *cg_p[2], *cg_v, *cg_q;        // CG search directions / operator images
     double *cg_z2;                        // second residual buffer of the forward CG (z ping-pongs r <-> cg_z2)
+    double *xf;                           // finished dphi of a Newton solve (written by the back-substitution kernel)
+    int cg_last;                          // index of the last sweep schur_solve enqueued (-1: none), for dmu_ceiling()
     double *gpart2;                       // second half of gpart
     double *gpart3;                       // [2][B][gnblk + ns] partials of <z',z'>_Z of the stencil-free sweep
     double *gpart;                        // [B][gnblk] partials written by the GEMM epilogue
@@ -275,7 +277,7 @@ extern "C" vch2d_ctx *vch2d_create(const vch2d_params *p, int batch, int max_ste
     for (auto q : two)
         if (dalloc(q, 2 * bp, c->stream)) return fail("hipMalloc");
     double **one[] = {&c->w, &c->wnew, &c->mu0, &c->cphi, &c->cmu, &c->x, &c->r, &c->dmu, &c->t1, &c->t2,
-                      &c->cg_p[0], &c->cg_p[1], &c->cg_v, &c->cg_q, &c->cg_z2, &c->tmp[0], &c->tmp[1], &c->tmp[2], &c->tmp[3], &c->tmp[4], &c->tmp[5], &c->phiT, &c->phi0};
+                      &c->cg_p[0], &c->cg_p[1], &c->cg_v, &c->cg_q, &c->cg_z2, &c->xf, &c->tmp[0], &c->tmp[1], &c->tmp[2], &c->tmp[3], &c->tmp[4], &c->tmp[5], &c->phiT, &c->phi0};
     for (auto q : one)
         if (dalloc(q, bp, c->stream)) return fail("hipMalloc");
     if (dalloc(&c->wts_mass, G.plane, c->stream) || dalloc(&c->W_cost, G.plane, c->stream)) return fail("hipMalloc");
@@ -374,7 +376,7 @@ extern "C" void vch2d_destroy(vch2d_ctx *c) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     double *all[] = {c->phi_s, c->mu_s, c->Rphi_s, c->rhs_s, c->D_s, c->w, c->wnew, c->mu0, c->cphi, c->cmu, c->x,
-                     c->r, c->dmu, c->t1, c->t2, c->cg_p[0], c->cg_p[1], c->cg_v, c->cg_q, c->cg_z2, c->gpart, c->gpart3, c->tmp[0], c->tmp[1], c->tmp[2], c->tmp[3], c->tmp[4], c->tmp[5],
+                     c->r, c->dmu, c->t1, c->t2, c->cg_p[0], c->cg_p[1], c->cg_v, c->cg_q, c->cg_z2, c->xf, c->gpart, c->gpart3, c->tmp[0], c->tmp[1], c->tmp[2], c->tmp[3], c->tmp[4], c->tmp[5],
                      c->phiT, c->phi0, c->wts_mass, c->W_cost, c->part, c->hist_dev, c->alpha_dev, c->J_dev, c->Q1f,
                      c->Q2f, c->Q1s, c->Q2s, c->mf, c->ms, c->phi_hist, c->u_hist, c->u_trial, c->phi_trial, c->phiQ,
                      c->r_hist, c->p_hist, c->q_hist, c->cost_part, c->cost_lvl, c->tfrac_dev};
@@ -533,12 +535,13 @@ constexpr int CG_CHUNK = 24;      // iterations enqueued between two looks at th
 // Every kernel is gated per trajectory (lin_active / the per-iteration copies), so trajectories that are not
 // solving -- converged, frozen, or waiting for an Armijo trial -- keep their x.
 static int schur_solve(vch2d_ctx *c, double dt, int budget, bool look) {
+    c->cg_last = -1;
     if (budget <= 0) return 0;
     const double c0 = 1.0 / dt, c2 = 0.5 * c->P.kappa;
     double *zb[2] = {c->r, c->cg_z2};               // z_k lives in zb[k & 1]
     VCHCHK(precond(c, c->rhs_s, c->slot_stride, zb[0], 3, nullptr, c0, 0.0, 1.0, c2, 1));      // z = P^-1 rhs, <z,z>_Z
-    LAUNCH(k_fin_cg_init, dim3(c->B), dim3(64), c->st, c->gpart, c->gnblk);
     const bool spectral = c->use_fft && !c->half_f && !c->half_s;      // stencil-free sweep (k_cg_rows_fwd)
+    if (!spectral) LAUNCH(k_fin_cg_init, dim3(c->B), dim3(64), c->st, c->gpart, c->gnblk);     // else: inside the first sweep
     int done = 0;
     while (done < budget) {
         const int chunk = look ? std::min(budget - done, CG_CHUNK) : budget - done;
@@ -586,22 +589,40 @@ static int schur_solve(vch2d_ctx *c, double dt, int budget, bool look) {
             if (!any_lin_active(c)) break;
         }
     }
-    // the reduction point of the last enqueued iteration, then its step
-    if (spectral)
-        LAUNCH(k_fin_cg_step3, dim3(c->B), dim3(192), c->st, (const double *)c->gpart, (const double *)c->gpart2,
-               (const double *)(c->gpart3 + (size_t)((done - 1) & 1) * c->B * c->gnblk), c->gnblk, done - 1 >= 1 ? 1 : 0, (done - 1) & 1,
-               (done - 1) & 1, c->lin_maxit);
-    else
+    // the reduction point of the last enqueued sweep and its step: inside the back-substitution kernel on the spectral
+    // path (dmu_ceiling below), two small launches on the GEMM path
+    c->cg_last = done - 1;
+    if (!spectral) {
         LAUNCH(k_fin_cg_step, dim3(c->B), dim3(192), c->st, c->gpart, c->gpart2, c->gnblk, c->part, c->nblk, (done - 1) & 1,
                done - 1 >= 1 ? 1 : 0, (done - 1) & 1, (done - 1) & 1, c->lin_tol, c->lin_maxit);
-    LAUNCHC(PC_CG_UPDATE, k_cg_finish, c->grid, dim3(NTH), c->G, c->st, c->cg_p[0], c->cg_p[1], c->x);
+        LAUNCHC(PC_CG_UPDATE, k_cg_finish, c->grid, dim3(NTH), c->G, c->st, c->cg_p[0], c->cg_p[1], c->x);
+    }
+    return 0;
+}
+
+// After schur_solve: dphi -> c->xf, dmu = 2 (K dphi + R_phi), step ceiling, start of the Armijo loop (F2:377-396).
+static int dmu_ceiling(vch2d_ctx *c, int strict) {
+    const bool spectral = c->use_fft && !c->half_f && !c->half_s;
+    if (spectral && c->cg_last >= 0) {
+        const int last = c->cg_last, rd = last & 1;
+        FinSolveArgs f{c->gpart, c->gpart2, c->gpart3 + (size_t)rd * c->B * c->gnblk, c->gnblk, last >= 1 ? 1 : 0, rd, c->lin_maxit,
+                       c->cg_p[last & 1]};
+        LAUNCH(k_dmu_ceiling_fin, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, (const double *)c->x, f, (const double *)c->phi_s,
+               (const double *)c->D_s, (const double *)c->Rphi_s, c->dmu, c->xf, c->part);
+        LAUNCH(k_fin_ceiling, dim3(c->B), dim3(64), c->st, c->part, c->nblk, strict, rd ^ 1);
+    } else {
+        LAUNCH(k_dmu_ceiling, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->x, c->phi_s, c->D_s, c->Rphi_s, c->dmu, c->xf,
+               c->part);
+        LAUNCH(k_fin_ceiling, dim3(c->B), dim3(64), c->st, c->part, c->nblk, strict, -1);
+    }
+    c->cg_last = -1;
     return 0;
 }
 
 #define RESIDUAL_TRIAL()                                                                                                    \
     do {                                                                                                                    \
         LAUNCHC(PC_RESIDUAL, (k_residual<1>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s,     \
-                c->Rphi_s, c->rhs_s, c->D_s, c->mu0, c->x, c->dmu, c->cphi, c->cmu, dt, c->part);                           \
+                c->Rphi_s, c->rhs_s, c->D_s, c->mu0, c->xf, c->dmu, c->cphi, c->cmu, dt, c->part);                          \
         LAUNCH((k_fin_residual<1>), dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->hist_dev, c->P.kappa, dt, c->lin_tol, \
                eta_);                                                                                                      \
     } while (0)
@@ -629,9 +650,7 @@ static int newton_level(vch2d_ctx *c, double dt, const double *un, const double 
     if (c->spec) {
         for (int s = 0; s < c->spec_slots; ++s) {
             VCHCHK(schur_solve(c, dt, c->spec_cgb[s], false));
-            LAUNCH(k_dmu_ceiling, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->x, c->phi_s, c->D_s, c->Rphi_s,
-                   c->dmu, c->part);
-            LAUNCH(k_fin_ceiling, dim3(c->B), dim3(64), c->st, c->part, c->nblk, 1);
+            VCHCHK(dmu_ceiling(c, 1));
             RESIDUAL_TRIAL();
         }
     }
@@ -650,9 +669,7 @@ static int newton_level(vch2d_ctx *c, double dt, const double *un, const double 
     while (any_active()) {
         if (++guard > NEWTON_MAXIT + 2) return vch_fail(VCH_ERR_STATE, "newton_level: state machine did not terminate");
         VCHCHK(schur_solve(c, dt, cg_budget(c, true), true));
-        LAUNCH(k_dmu_ceiling, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->x, c->phi_s, c->D_s, c->Rphi_s,
-               c->dmu, c->part);
-        LAUNCH(k_fin_ceiling, dim3(c->B), dim3(64), c->st, c->part, c->nblk, 0);
+        VCHCHK(dmu_ceiling(c, 0));
         int tguard = 0;
         do {
             RESIDUAL_TRIAL();
@@ -831,11 +848,9 @@ extern "C" int vch2d_jacobian_solve(vch2d_ctx *c, const double *phi_new, double 
         for (auto &S : tmp) { S.newton_active = 1; S.need_trial = 0; }
         HIPCHK(hipMemcpy(c->st, tmp.data(), sizeof(TrajState) * c->B, hipMemcpyHostToDevice));
     }
-    LAUNCH(k_dmu_ceiling, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->x, c->phi_s, c->D_s, c->Rphi_s, c->dmu,
-           c->part);
-    LAUNCH(k_fin_ceiling, dim3(c->B), dim3(64), c->st, c->part, c->nblk, 0);
+    VCHCHK(dmu_ceiling(c, 0));
     HIPCHK(hipEventRecord(c->ev1, c->stream));
-    VCHCHK(d2h(c, dphi, c->x, c->B));
+    VCHCHK(d2h(c, dphi, c->xf, c->B));
     VCHCHK(d2h(c, dmu, c->dmu, c->B));
     VCHCHK(sync_state(c));
     float ms = 0;
@@ -863,14 +878,13 @@ static int adjoint_solve_cg(vch2d_ctx *c, double dt, int budget, bool look) {
         const Geom &G = c->G;
         const int ns = G.ns, nf = G.nf;
         double *rb[2] = {c->r, c->cg_z2}, *y = c->cg_v;
-        LAUNCH(k_fin_adj_init, dim3(c->B), dim3(64), c->st, (const double *)c->part, c->nblk, c->lin_tol, c->lin_maxit);
         int done = 0;
         while (done < budget) {
             const int chunk = look ? std::min(budget - done, CG_CHUNK) : budget - done;
             for (int j = 0; j < chunk; ++j, ++done) {
                 double *pn = c->cg_p[done & 1], *po = c->cg_p[(done + 1) & 1];
                 AdjSweepArgs a{done == 0 ? rb[0] : rb[(done + 1) & 1], c->cg_q, po, y, rb[done & 1], pn, c->cmu,
-                               c->gpart, c->gpart2, c->gpart3, done, c->lin_maxit, c->B};
+                               c->gpart, c->gpart2, c->gpart3, done, c->lin_maxit, c->B, c->part, c->nblk, c->lin_tol};
 #define ADJ_ROWS(FIRST_, C_, LG_)                                                                                       \
     do {                                                                                                                \
         const int rpw = 2 * (C_ >> c->fax.logL);                                                                        \
@@ -1026,9 +1040,8 @@ static int forward_core(vch2d_ctx *c, const double *u_dev, int u_rows, const dou
         VCHCHK(newton_level(c, dt[step], un, unp1, hs, nullptr, true));
         // clip, mass fix, store (F2:562-585)
         LAUNCH(k_mass, c->grid, dim3(NTH), c->G, c->st, c->slot_stride, c->phi_s, c->wts_mass, 1, c->part);
-        LAUNCH(k_fin_mass, dim3(c->B), dim3(64), c->st, c->part, c->nblk, 0);
         LAUNCH(k_post, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s,
-               hist_out ? hist_out + (long)(step + 1) * c->G.plane : (double *)nullptr, hs);
+               hist_out ? hist_out + (long)(step + 1) * c->G.plane : (double *)nullptr, hs, (const double *)c->part);
         std::swap(c->w, c->wnew);
     }
     return 0;

@@ -569,24 +569,60 @@ __device__ __forceinline__ void cg_sums3(const double *__restrict__ g1, const do
     __syncthreads();
 }
 
-// The reduction point of the LAST enqueued sweep of the stencil-free form (cf. k_fin_cg_step): 192 threads.
-__global__ void k_fin_cg_step3(TrajState *st, const double *__restrict__ gpart, const double *__restrict__ gpart2,
-                               const double *__restrict__ gpart3_rd, int gnblk, int direct, int pbuf, int rd, int maxit) {
-    const int b = blockIdx.x;
-    TrajState &S = st[b];
+// End of a stencil-free forward solve, fused with the back substitution (cf. k_dmu_ceiling): every workgroup resolves the
+// reduction point of the last enqueued sweep (copy rd -> rd ^ 1, recorded by workgroup 0; lin_active itself is taken
+// over by k_fin_ceiling), forms dphi = x + alpha p_last on its haloed tile, stores it to x_out, and goes on with
+// dmu = 2 (K dphi + R_phi) and the step-ceiling ratio.
+struct FinSolveArgs {
+    const double *gpart, *gpart2, *gpart3_rd;
+    int gnblk, direct, rd, maxit;
+    const double *p_last;                 // the direction of the last sweep
+};
+__global__ __launch_bounds__(NTH) void k_dmu_ceiling_fin(Geom G, Phys P, TrajState *__restrict__ st, long slot_stride,
+                                                         const double *__restrict__ x, FinSolveArgs f,
+                                                         const double *__restrict__ phi_s, const double *__restrict__ D_s,
+                                                         const double *__restrict__ Rphi_s, double *__restrict__ dmu,
+                                                         double *__restrict__ x_out, double *__restrict__ part) {
+    TILE_COORDS;
+    if (!st[b].newton_active || st[b].need_trial) return;
+    __shared__ double sx[(TY + 2) * (TX + 2)];
+    __shared__ double sred[NPART * 4];
     __shared__ double s3[3];
-    if (!S.lin_active) return;
-    if (!S.ci_active[rd]) {                  // converged earlier: its last step is already in x
-        if (threadIdx.x == 0) { S.lin_active = 0; S.cg_pending = 0; }
-        return;
+    constexpr int W = TX + 2;
+    const long pb = b * G.plane;
+    const int slot = st[b].slot;
+    double alpha = 0.0;
+    if (st[b].lin_active) {
+        if (!st[b].ci_active[f.rd]) {                      // converged in an earlier sweep: its last step is in x already
+            if (blk == 0 && threadIdx.x == 0) st[b].ci_active[f.rd ^ 1] = 0;
+        } else {
+            const double gamma0 = st[b].cg_gamma0, gamma_old = st[b].ci_gamma[f.rd], tol = st[b].lin_reltol;
+            const int it_old = st[b].ci_it[f.rd];
+            cg_sums3<NTH>(f.gpart, f.gpart2, f.direct ? f.gpart3_rd : nullptr, f.gnblk, b, s3);
+            const CgNext n = cg_next(s3[0], s3[1], f.direct ? s3[2] : gamma_old, gamma0, it_old, tol, f.maxit);
+            if (blk == 0 && threadIdx.x == 0) cg_record(st[b], n, f.rd ^ 1);
+            alpha = n.breakdown ? 0.0 : n.alpha;
+        }
     }
-    cg_sums3<192>(gpart, gpart2, direct ? gpart3_rd : nullptr, gnblk, b, s3);
-    if (threadIdx.x != 0) return;
-    const CgNext n = cg_next(s3[0], s3[1], direct ? s3[2] : S.ci_gamma[rd], S.cg_gamma0, S.ci_it[rd], S.lin_reltol, maxit);
-    cg_record(S, n, rd ^ 1);
-    S.cg_pending = n.breakdown ? 0 : 1;
-    S.cg_pbuf = pbuf;
-    S.lin_active = n.active;
+    if (alpha != 0.0) load_tile_axpy<1>(sx, x + pb, f.p_last + pb, alpha, G, c0, r0);
+    else load_tile<1>(sx, x + pb, G, c0, r0);
+    __syncthreads();
+    double acc[1] = {1e300};
+    for (int k = 0; k < TY / 4; ++k) {
+        int ly = ly0 + 4 * k, r = r0 + ly, c = c0 + lx;
+        if (r < G.ns && c < G.nf) {
+            int p = (ly + 1) * W + lx + 1;
+            long o = pb + (long)r * G.pitch + c, os = slot * slot_stride + o;
+            double d = sx[p];
+            x_out[o] = d;
+            dmu[o] = 2.0 * ((-0.5 * P.kappa * lap_at<W>(sx, p, G.ax, G.ay) + D_s[os] * d) + Rphi_s[os]);
+            double ph = phi_s[os];
+            if (d > 0.0) acc[0] = fmin(acc[0], (1.0 - DELTA_SEP - ph) / d);
+            else if (d < 0.0) acc[0] = fmin(acc[0], (-1.0 + DELTA_SEP - ph) / d);
+        }
+    }
+    const int op[1] = {1};
+    block_reduce_store<1>(acc, op, sred, part + ((long)b * nblk + blk) * NPART);
 }
 
 template <int FIRST, int C, int LOGL>
@@ -603,7 +639,31 @@ __global__ __launch_bounds__((FftThreads<C, LOGL>::T)) void k_cg_rows_fwd(Geom G
     const long pb = b * G.plane;
     double alpha = 0.0, beta = 0.0;
     if (FIRST) {
-        if (!st[b].ci_active[0]) return;
+        // start of a solve (what k_fin_cg_init does on the GEMM path): workgroup 0 of the trajectory sums
+        // gamma0 = <z0,z0>_Z from the partials of the transform that produced z0 and arms the per-sweep state
+        const int active = st[b].lin_active;
+        if (blockIdx.x == 0 && tid < 64) {
+            double g = 0.0;
+            if (active)
+                for (int t = tid; t < (int)gridDim.x; t += 64) g += a.gpart[(long)b * gridDim.x + t];
+            g = wave_sum(g);
+            if (tid == 0) {
+                TrajState &S = st[b];
+                S.cg_pending = 0;
+                if (!active) {
+                    S.ci_active[0] = 0;
+                } else {
+                    S.cg_gamma = S.cg_gamma0 = g;
+                    S.cg_beta = 0.0;
+                    S.lin_it = 0;
+                    S.lin_rel = 1.0;
+                    S.ci_active[0] = 1;
+                    S.ci_it[0] = 0;
+                    S.ci_gamma[0] = g;
+                }
+            }
+        }
+        if (!active) return;
     } else {
         if (!st[b].ci_active[rd]) {
             if (blockIdx.x == 0 && tid == 0) {             // hand the (finished) state on to the other copy
@@ -747,6 +807,9 @@ struct AdjSweepArgs {
     const double *gpart, *gpart2;         // [B][gnblk] partials of <ph,q>_Z', <q,q>_Z' of the previous sweep
     double *gpart3;                       // [2][B][gnblk][2] partials of <r',r'>_Z' and ||r'||^2, copy = sweep parity
     int it, maxit, nbatch;
+    const double *part;                   // first sweep: partials {<r0,r0>_Z', ||r0||^2} of k_adj_op<1>, stencil-tile layout
+    int nblk;
+    double tol;
 };
 
 struct CgNextAdj {
@@ -811,34 +874,6 @@ __device__ __forceinline__ void adj_sums4(const double *__restrict__ g1, const d
     __syncthreads();
 }
 
-// Start of an adjoint solve, after k_adj_op<1> (r0 = rhs - A x0 with the partials {<r0,r0>_Z', ||r0||^2} in the
-// stencil-tile layout `part`): gamma0, the 2-norm of r0 and the per-sweep state copies.
-__global__ void k_fin_adj_init(TrajState *st, const double *__restrict__ part, int nblk, double tol, int maxit) {
-    const int b = blockIdx.x;
-    TrajState &S = st[b];
-    if (threadIdx.x == 0) {
-        S.cg_pending = 0;
-        if (!S.lin_active) S.ci_active[0] = S.lin_took = 0;
-    }
-    if (!S.lin_active) return;
-    const double g = fin_sum1(part, nblk, b, NPART, 0), r2 = fin_sum1(part, nblk, b, NPART, 1);
-    if (threadIdx.x != 0) return;
-    S.cg_gamma = S.cg_gamma0 = g;
-    S.cg_beta = 0.0;
-    S.lin_it = 0;
-    S.lin_reltol = tol;
-    S.aux[0] = r2;                                        // ||r0||^2, the 2-norm the first reduction point scales
-    S.lin_rel = S.lin_r0 > 0.0 ? sqrt(r2) / S.lin_r0 : 0.0;
-    if (!(S.lin_rel > tol) || !(g > 0.0)) {               // the initial guess already solves the system
-        S.lin_active = 0;
-        if (S.lin_rel > S.lin_maxrel) S.lin_maxrel = S.lin_rel;
-    }
-    S.ci_active[0] = S.lin_active;
-    S.lin_took = S.lin_active;
-    S.ci_it[0] = 0;
-    S.ci_gamma[0] = g;
-}
-
 // The reduction point of the LAST enqueued adjoint sweep; leaves the step pending for k_cg_finish (on y).
 __global__ void k_fin_adj_step(TrajState *st, const double *__restrict__ gpart, const double *__restrict__ gpart2,
                                const double *__restrict__ gpart3_rd, int gnblk, int direct, int pbuf, int rd, int maxit) {
@@ -875,7 +910,51 @@ __global__ __launch_bounds__((FftThreads<C, LOGL>::T)) void k_adj_rows_fwd(Geom 
     const long pb = b * G.plane;
     double alpha = 0.0, beta = 0.0;
     if (FIRST) {
-        if (!st[b].ci_active[0]) return;
+        // start of an adjoint solve: every workgroup sums gamma0 = <r0,r0>_Z' and ||r0||^2 (the partials of k_adj_op<1>),
+        // so all of them know whether the start value already solves the system; workgroup 0 records the state
+        const int pending = st[b].lin_active;
+        const double rhsn = st[b].lin_r0;
+        double g = 0.0, r2 = 0.0;
+        if (pending) {
+            if (tid < 64) {
+                for (int t = tid; t < a.nblk; t += 64) {
+                    g += a.part[((long)b * a.nblk + t) * NPART];
+                    r2 += a.part[((long)b * a.nblk + t) * NPART + 1];
+                }
+                g = wave_sum(g);
+                r2 = wave_sum(r2);
+                if (tid == 0) {
+                    s4[0] = g;
+                    s4[1] = r2;
+                }
+            }
+            __syncthreads();
+            g = s4[0];
+            r2 = s4[1];
+        }
+        const double rel = rhsn > 0.0 ? sqrt(r2) / rhsn : 0.0;
+        const int start = pending && (rel > a.tol) && (g > 0.0);
+        if (blockIdx.x == 0 && tid == 0) {
+            TrajState &S = st[b];
+            S.cg_pending = 0;
+            if (pending) {
+                S.cg_gamma = S.cg_gamma0 = g;
+                S.cg_beta = 0.0;
+                S.lin_it = 0;
+                S.lin_reltol = a.tol;
+                S.aux[0] = r2;
+                S.lin_rel = rel;
+                if (!start) {
+                    S.lin_active = 0;
+                    if (rel > S.lin_maxrel) S.lin_maxrel = rel;
+                }
+                S.ci_it[0] = 0;
+                S.ci_gamma[0] = g;
+            }
+            S.ci_active[0] = start;
+            S.lin_took = start;
+        }
+        if (!start) return;
     } else {
         if (!st[b].ci_active[rd]) {
             if (blockIdx.x == 0 && tid == 0) {

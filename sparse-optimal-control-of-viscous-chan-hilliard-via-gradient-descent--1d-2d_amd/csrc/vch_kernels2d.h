@@ -383,12 +383,14 @@ __global__ __launch_bounds__(NTH) void k_schur(Geom G, Phys P, const TrajState *
 // substitution of the Schur reduction); per workgroup min over nodes of the step-ceiling
 // ratio ((+-(1-delta) - phi)/dphi, F2:381-387).
 // ---------------------------------------------------------------------------------
+// x_out = the finished dphi.  The kernel reads x (+ alpha p for the fused form of vch_fft.h, k_dmu_ceiling_fin, which also
+// resolves the last reduction point of the solve) on the haloed tile and never writes what a neighbour reads.
 __global__ __launch_bounds__(NTH) void k_dmu_ceiling(Geom G, Phys P, const TrajState *__restrict__ st,
                                                      long slot_stride, const double *__restrict__ x,
                                                      const double *__restrict__ phi_s,
                                                      const double *__restrict__ D_s,
                                                      const double *__restrict__ Rphi_s, double *__restrict__ dmu,
-                                                     double *__restrict__ part) {
+                                                     double *__restrict__ x_out, double *__restrict__ part) {
     TILE_COORDS;
     const TrajState S = st[b];
     if (!S.newton_active || S.need_trial) return;
@@ -405,6 +407,7 @@ __global__ __launch_bounds__(NTH) void k_dmu_ceiling(Geom G, Phys P, const TrajS
             int p = (ly + 1) * W + lx + 1;
             long o = pb + (long)r * G.pitch + c, os = S.slot * slot_stride + o;
             double d = sx[p];
+            x_out[o] = d;
             dmu[o] = 2.0 * ((-0.5 * P.kappa * lap_at<W>(sx, p, G.ax, G.ay) + D_s[os] * d) + Rphi_s[os]);
             double ph = phi_s[os];
             if (d > 0.0) acc[0] = fmin(acc[0], (1.0 - DELTA_SEP - ph) / d);
@@ -505,16 +508,34 @@ __global__ __launch_bounds__(NTH) void k_mass(Geom G, const TrajState *__restric
     block_reduce_store<2>(acc, op, sred, part + ((long)b * nblk + blk) * NPART);
 }
 
+// k_post sums the per-workgroup partials of k_mass itself (every workgroup, the same numbers in the same order: the
+// first wavefront strides over them like fin_reduce does), so no `fin` launch sits between the two passes.
 __global__ __launch_bounds__(NTH) void k_post(Geom G, Phys P, const TrajState *__restrict__ st, long slot_stride,
                                               double *__restrict__ phi_s, double *__restrict__ hist_level,
-                                              long hist_stride) {
+                                              long hist_stride, const double *__restrict__ part) {
     TILE_COORDS;
     const TrajState S = st[b];
     if (S.frozen) return;
+    __shared__ double sm[2];
+    if (threadIdx.x < 64) {
+        double a0 = 0.0, a1 = 0.0;
+        for (int t = threadIdx.x; t < nblk; t += 64) {
+            a0 += part[((long)b * nblk + t) * NPART];
+            a1 += part[((long)b * nblk + t) * NPART + 1];
+        }
+        a0 = wave_sum(a0);
+        a1 = wave_sum(a1);
+        if (threadIdx.x == 0) {
+            sm[0] = a0;
+            sm[1] = a1;
+        }
+    }
+    __syncthreads();
+    const double mass_err = sm[0] - S.mass0, Wint = sm[1];
     const double hi = 1.0 - DELTA_SEP;
-    const bool fix = fabs(S.mass_err) > 1e-16;
-    const bool interior_ok = S.Wint > 0.0;
-    const double shift = fix ? (interior_ok ? S.mass_err / S.Wint : S.mass_err / P.LxLy) : 0.0;
+    const bool fix = fabs(mass_err) > 1e-16;
+    const bool interior_ok = Wint > 0.0;
+    const double shift = fix ? (interior_ok ? mass_err / Wint : mass_err / P.LxLy) : 0.0;
     for (int k = 0; k < TY / 4; ++k) {
         int r = r0 + ly0 + 4 * k, c = c0 + lx;
         if (r < G.ns && c < G.nf) {
@@ -1143,10 +1164,17 @@ __global__ void k_fin_cg_beta(TrajState *st, const double *__restrict__ part, in
 // After k_dmu_ceiling: the step ceiling (F2:383-391) and the start of the Armijo loop.
 // strict: a solve that the enqueued sweeps did not finish is left as it is (lin_active stays set, no trial is armed), so the
 // next solve slot of the schedule -- or the host's continuation loop -- runs it again with the budget it needs.
-__global__ void k_fin_ceiling(TrajState *st, const double *__restrict__ part, int nblk, int strict) {
+// fin_copy >= 0 (after k_dmu_ceiling_fin): the solve's last reduction point was resolved by that kernel into copy
+// fin_copy of the per-sweep state, from which lin_active is taken over here.
+__global__ void k_fin_ceiling(TrajState *st, const double *__restrict__ part, int nblk, int strict, int fin_copy) {
     const int b = blockIdx.x;
     TrajState &S = st[b];
     if (!S.newton_active || S.need_trial) return;
+    if (fin_copy >= 0 && S.lin_active) {
+        __syncthreads();                                       // every thread has read lin_active
+        if (threadIdx.x == 0) S.lin_active = S.ci_active[fin_copy];
+        __syncthreads();
+    }
     if (strict && S.lin_active) return;
     double v[NPART];
     const int op[NPART] = {1, 0, 0, 0, 0, 0};
