@@ -226,6 +226,7 @@ def run(a, world, rank, local, dist):
     import queue
     import threading
     it_done = [0]
+    last_cost = J0[:, 4].copy()          # a stopped trajectory reports no new cost: its last one stands
 
     def run_iterations(n):
         """n PGD iterations of every context.  The trajectories of different contexts are independent
@@ -256,7 +257,8 @@ def run(a, world, rank, local, dist):
             else:
                 J = np.zeros((B, 5))
                 c = np.concatenate([x["cost"] for x in rs])[:, 0]
-                J[:, 4] = np.where(np.isnan(c), 0.0, c)      # a stopped trajectory reports no new cost
+                last_cost[:] = np.where(np.isnan(c), last_cost, c)
+                J[:, 4] = last_cost
                 Jsum = par.allreduce_cost(J, dist, dev)
             it_done[0] += 1
             outs.append(dict(cost_sum=float(Jsum[4]), attempts=int(sum(int(x["attempts"].sum()) for x in rs)),

@@ -8,7 +8,7 @@ O=gpurun_out/r2_ab.log
 for TAG in "$@"; do
   export VCH_LIB=$PWD/$PK/libvch_$TAG.so
   echo "== $TAG" >> $O
-  python -m pytest tests/test_gpu_2d.py -q -x -k "spectral or newton_512 or forward_backward or bitwise" 2>&1 | tail -2 >> $O
-  for B in 8 4 1; do python scripts/fwd_stats.py 512 1000 $B 2>&1 | grep -E "^forward|^backward" | tail -2 | sed "s/^/B=$B /" | cut -c1-60,200-330 >> $O; done
+  python -m pytest tests/test_gpu_2d.py -q -x -k "spectral or forward_backward" 2>&1 | tail -1 >> $O
+  for B in 8 4 1; do python scripts/fwd_stats.py 512 1000 $B 2>&1 | grep -E "^forward|^backward" | tail -2 | sed "s/^/B=$B /" | cut -c1-20,240-330 >> $O; done
 done
 cat $O

@@ -34,12 +34,20 @@ class CostComm:
         from . import _lib
         self.lib = _lib.load()
         ident = (C.c_ubyte * 128)()
+        err = None
         if rank == 0:
-            _lib.check(self.lib.vch_comm_unique_id(ident))
+            try:
+                _lib.check(self.lib.vch_comm_unique_id(ident))
+            except Exception as exc:          # the other ranks must still get their broadcast
+                err = str(exc)
         if world > 1:
-            box = [bytes(ident)]
+            box = [None if err else bytes(ident)]
             dist.broadcast_object_list(box, src=0)
+            if box[0] is None:
+                raise _lib.VchError("rank 0 could not create an RCCL unique id" + (": " + err if err else ""))
             ident = (C.c_ubyte * 128).from_buffer_copy(box[0])
+        elif err:
+            raise _lib.VchError(err)
         self.h = self.lib.vch_comm_create(ident, int(rank), int(world), int(device))
         if not self.h:
             raise _lib.VchError("vch_comm_create failed: " + _lib.last_error())

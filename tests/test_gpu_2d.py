@@ -412,7 +412,10 @@ def test_newton_512_vs_reference_history(V, O2):
         phi, mu, hist, st = e.newton_raphson(phi, mu, w, w, 1e-3)
         ref = g[f"hist{step}"]
         assert len(hist) == len(ref), (hist, ref, st)
-        assert np.allclose(hist[:-1], ref[:-1], rtol=1e-4), (hist, ref)
+        # norms above the evaluation floor (|L mu| eps ~ 6e-7 at 512^2, the level of the last entry) agree to solver
+        # round-off relative to the FIRST norm (9e9 -> 2.0 is a reduction by 2e-10: the second entry is itself the
+        # round-off residual of the first linear solve, hence rtol 1e-4 and not 1e-9)
+        assert np.allclose(hist[:-1], ref[:-1], rtol=1e-4), ("norm history differs beyond the round-off floor", hist, ref)
         assert hist[-1] < 1e-6
         assert relerr(phi[::8, ::8], g["sub"][step + 1]) < SOLVE, st
 
