@@ -75,6 +75,10 @@ __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
 #ifndef FFT_ROWS_INGEST
 #define FFT_ROWS_INGEST 1
 #endif
+#ifndef CG_ROWS_STAGED
+#define CG_ROWS_STAGED 1      // first pass of a CG sweep: visit every node once and stage the even extension in LDS (0: feed the
+                              // first FFT pass from global memory, which reads each operand twice; -5 % on the march, r02_fft_variants.txt)
+#endif
 #ifndef FFT_COLS_INGEST
 #define FFT_COLS_INGEST 0
 #endif
@@ -750,7 +754,20 @@ __global__ __launch_bounds__((FftThreads<C, LOGL>::T)) void k_cg_rows_fwd(Geom G
                 return make_double2(node_(ra, m, owner), node_(ra + 1, m, owner));
             }
         };
+#if CG_ROWS_STAGED
+        // every node once (no second visit for the mirror half of the even extension): stage the image, then transform
+        for (int idx = tid; idx < nfft * n1; idx += T) {
+            const int f = nfft == 1 ? 0 : idx / n1, j = idx - f * n1;
+            const int ra = row0 + 2 * f;
+            const double2 v = make_double2(node(ra, j, true), node(ra + 1, j, true));
+            buf[swz<LOGL>(f * L + j)] = v;
+            if (j > 0 && j < N) buf[swz<LOGL>(f * L + L - j)] = v;
+        }
+        __syncthreads();
+        fft_lds<C, LOGL>(buf, ax, Emit{put, row0, G.ns});
+#else
         fft_lds<C, LOGL>(buf, ax, Emit{put, row0, G.ns}, Ingest{node, row0});
+#endif
     } else {
         const float inv_n1 = 1.0f / (float)n1;
         for (int idx = tid; idx < nfft * n1; idx += T) {
@@ -1044,7 +1061,20 @@ __global__ __launch_bounds__((FftThreads<C, LOGL>::T)) void k_adj_rows_fwd(Geom 
                 return make_double2(node_(ra, m, owner), node_(ra + 1, m, owner));
             }
         };
+#if CG_ROWS_STAGED
+        // every node once (no second visit for the mirror half of the even extension): stage the image, then transform
+        for (int idx = tid; idx < nfft * n1; idx += T) {
+            const int f = nfft == 1 ? 0 : idx / n1, j = idx - f * n1;
+            const int ra = row0 + 2 * f;
+            const double2 v = make_double2(node(ra, j, true), node(ra + 1, j, true));
+            buf[swz<LOGL>(f * L + j)] = v;
+            if (j > 0 && j < N) buf[swz<LOGL>(f * L + L - j)] = v;
+        }
+        __syncthreads();
+        fft_lds<C, LOGL>(buf, ax, Emit{put, row0, G.ns});
+#else
         fft_lds<C, LOGL>(buf, ax, Emit{put, row0, G.ns}, Ingest{node, row0});
+#endif
     } else {
         const float inv_n1 = 1.0f / (float)n1;
         for (int idx = tid; idx < nfft * n1; idx += T) {
