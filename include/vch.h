@@ -242,8 +242,9 @@ int vch2d_free_energy(vch2d_ctx *ctx, const double *phi_hist, int rows, const do
  *   2 Newton residual  3 adjoint operator  4 CG vector update  5 adjoint right-hand side  6 cost integrands
  *   7 gradient+prox  8 DCT row pass (forward)  9 DCT column pass (forward, multiplier, inverse)
  *   10 DCT row pass (inverse, with the CG dot products)  11 first sweep of a solve (k_schur_p<1>)
- *   12 first pass of a CG sweep (k_cg_rows_fwd: CG vector updates + Delta p + forward row DCT)  13 the same, first sweep */
-#define VCH_PROF_CLASSES 14
+ *   12 first pass of a CG sweep (k_cg_rows_fwd: CG vector updates + Delta p + forward row DCT)  13 the same, first sweep
+ *   14 an empty kernel launched 256 times by _begin: the cost of an event pair itself */
+#define VCH_PROF_CLASSES 15
 int vch2d_prof_begin(vch2d_ctx *ctx, int max_launches);
 int vch2d_prof_end(vch2d_ctx *ctx, double *ms_out, int64_t *count_out, int ncls);
 

@@ -119,7 +119,10 @@ struct vch2d_ctx {
 // Kernel classes for the in-situ timing of vch2d_prof_begin/_end.
 enum { PC_SCHUR_P = 0, PC_GEMM = 1, PC_RESIDUAL = 2, PC_ADJ_Q = 3, PC_CG_UPDATE = 4, PC_ADJ_RHS = 5, PC_COST = 6,
        PC_PROX = 7, PC_DCT_R0 = 8, PC_DCT_C = 9, PC_DCT_R3 = 10, PC_SCHUR_P1 = 11, PC_CG_ROWS = 12, PC_CG_ROWS1 = 13,
-       PC_NCLS = 14 };
+       PC_NOOP = 14, PC_NCLS = 15 };
+
+// an empty kernel: what an event pair measures around it is the cost of the pair itself (vch2d_prof_begin)
+__global__ void k_noop() {}
 
 // launch with an event pair around it when profiling is on (events are recorded on the
 // engine's own stream, the one the kernel is launched on)
@@ -1671,6 +1674,8 @@ extern "C" int vch2d_prof_begin(vch2d_ctx *c, int max_launches) {
     c->prof_used = 0;
     c->prof_cls.clear();
     c->prof_on = true;
+    // calibration: event pairs around an empty kernel (class 14), so that the caller can take the pair's own cost off
+    for (int k = 0; k < 256; ++k) LAUNCHC(PC_NOOP, k_noop, dim3(1), dim3(64));
     return 0;
 }
 
