@@ -20,7 +20,7 @@ alg = {"k_cg_rows_fwd<0, 1024, 10>": (40, 32, "stream"), "k_cg_rows_fwd<1, 1024,
        "k_dct_rows<4, 1024, 10>": (24, 8, "stream"), "k_dct_rows<5, 1024, 10>": (24, 8, "stream"),
        "k_dct_cols<1024, 10>": (8, 8, "stream"), "k_adj_rows_fwd<0, 1024, 10>": (40, 32, "stream"),
        "k_residual<1>": (48, 40, "tile"), "k_residual<0>": (32, 32, "tile"), "k_prepare": (40, 32, "tile"),
-       "k_dmu_ceiling": (32, 8, "tile"), "k_adj_rhs": (48, 16, "tile"), "k_schur_p<0>": (40, 32, "tile"),
+       "k_dmu_ceiling_fin": (40, 16, "tile"), "k_adj_rhs": (48, 16, "tile"), "k_schur_p<0>": (40, 32, "tile"),
        "k_copy_plane": (8, 8, "tile"), "k_grad_prox": (16, 8, "stream"), "k_cost": (24, 0, "stream")}
 res = {}
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
