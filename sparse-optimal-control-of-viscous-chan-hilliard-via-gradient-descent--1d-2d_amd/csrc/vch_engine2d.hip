@@ -1145,6 +1145,8 @@ static int backward_pass(vch2d_ctx *c, const double *phi_hist_dev, int M, const 
 
 static int backward_core(vch2d_ctx *c, const double *phi_hist_dev, int M, const double *t_hist, double b1, double b2,
                          const double *phiQ_dev, const double *phiT_dev, double *r_out, double *p_out, double *q_out) {
+    if (getenv("VCH_ADJ_SAFE"))       // diagnostics: the fallback schedule (a look and the rigorous budget at every step)
+        return backward_pass(c, phi_hist_dev, M, t_hist, b1, b2, phiQ_dev, phiT_dev, r_out, p_out, q_out, true);
     VCHCHK(backward_pass(c, phi_hist_dev, M, t_hist, b1, b2, phiQ_dev, phiT_dev, r_out, p_out, q_out, false));
     VCHCHK(sync_state(c));
     bool redo = false;

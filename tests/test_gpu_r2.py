@@ -405,3 +405,51 @@ def test_one_look_per_step_and_inexact_newton(V, O2):
     assert st3["linear_iters"] > st["linear_iters"], (st, st3)
     assert counts(st3) == counts(st), (st, st3)
     assert np.max(np.abs(ph3 - ph)) < 1e-10
+
+
+def test_adjoint_sweep_schedule_independent(V, O2):
+    """The adjoint sweep's launch schedule (a look every 8 steps, sweeps per step from the longest solve so far) against
+    its fallback (VCH_ADJ_SAFE=1: a look and the rigorous sweep budget at every step): same p, q, r to solver round-off,
+    every solve converged (max_lin_relres at the 1e-15 tolerance), far fewer looks."""
+    import os
+    N, M = 128, 24
+    t, dts = V.time_grid(M * 1e-3, 1e-3)
+    phi0 = np.stack([O2.init_phi_random(N, N, 1e-2, amp=0.1, seed=42 + i) for i in range(2)])
+    phi_T = np.stack([_phi_T(N)] * 2)
+    e = V.Engine2D(Nx=N, Ny=N, batch=2, max_steps=M)
+    ph, _ = e.forward(phi0, dts)
+    p, q, r, st = e.backward(ph, t, 5.0, 10.0, None, phi_T)
+    assert st["max_lin_relres"] < 2e-15 and st["host_syncs"] <= M // 8 + 6, st
+    os.environ["VCH_ADJ_SAFE"] = "1"
+    try:
+        p2, q2, r2, st2 = e.backward(ph, t, 5.0, 10.0, None, phi_T)
+    finally:
+        del os.environ["VCH_ADJ_SAFE"]
+    assert st2["host_syncs"] >= M
+    assert relerr(p, p2) < 1e-12 and relerr(q, q2) < 1e-10 and relerr(r, r2) < 1e-10, (st, st2)
+
+
+def test_cost_collective_through_the_c_abi(V, O2):
+    """vch_comm_*: RCCL communicator owned by the library (one rank here), all-reduce of the device-resident cost
+    scalars of two contexts, for a given iteration index and for the current iterate; the ring keeps earlier iterations."""
+    N, T, dt = 16, 0.05, 1e-2
+    t, dts = V.time_grid(T, dt)
+    engs = [V.Engine2D(Nx=N, Ny=N, batch=2, max_steps=len(dts)) for _ in range(2)]
+    J0 = []
+    for k, e in enumerate(engs):
+        phi0 = np.stack([O2.init_phi_random(N, N, 1e-2, amp=0.1, seed=42 + 2 * k + i) for i in range(2)])
+        J0.append(e.pgd_init(phi0, np.stack([_phi_T(N)] * 2), t, V.make_opt(), ramp=True, T=T))
+    comm = V.parallel.CostComm(0, 1, 0)
+    try:
+        assert np.allclose(comm.allreduce(engs, -1), np.concatenate(J0).sum(axis=0), rtol=1e-14)      # J(u0), set by pgd_init
+        outs = [e.pgd_iterate(2) for e in engs]
+        per_it = [sum(o["cost"][:, it].sum() for o in outs) for it in range(2)]
+        for it in range(2):
+            assert abs(comm.allreduce(engs, it)[4] / per_it[it] - 1) < 1e-14
+        assert abs(comm.allreduce(engs, -1)[4] / per_it[1] - 1) < 1e-14
+        with pytest.raises(Exception):
+            comm.allreduce(engs, 5)                     # an iteration that has not happened
+    finally:
+        comm.close()
+        for e in engs:
+            e.close()
