@@ -84,26 +84,32 @@ __device__ __forceinline__ Row row0(const SysArgs &S, int i) {
     return R;
 }
 
-// one cyclic-reduction step: eliminate the neighbours lo and hi (if present) from row mid
-__device__ __forceinline__ Row cr_reduce(const Row *lo, const Row &mid, const Row *hi) {
+// one cyclic-reduction step: eliminate the neighbours lo and hi (where present) from row mid.  The neighbours are
+// passed by value with presence flags: a `present ? &row : nullptr` argument makes the compiler keep the rows in
+// private (scratch) memory, 232 bytes per lane and a memory round trip per field (profiles/r02_1d_scratch.txt).
+__device__ __forceinline__ Row cr_reduce(bool hl, const Row &lo, const Row &mid, bool hh, const Row &hi) {
     Row R = mid;
     R.A = M2{0, 0, 0, 0};
     R.C = M2{0, 0, 0, 0};
-    if (lo) {
-        const M2 al = mneg(mm(mid.A, minv(lo->B)));
-        R.A = mm(al, lo->A);
-        R.B = madd(R.B, mm(al, lo->C));
-        const V2 t = mv(al, lo->d);
+    if (hl) {
+        const M2 al = mneg(mm(mid.A, minv(lo.B)));
+        R.A = mm(al, lo.A);
+        R.B = madd(R.B, mm(al, lo.C));
+        const V2 t = mv(al, lo.d);
         R.d.x += t.x; R.d.y += t.y;
     }
-    if (hi) {
-        const M2 ga = mneg(mm(mid.C, minv(hi->B)));
-        R.C = mm(ga, hi->C);
-        R.B = madd(R.B, mm(ga, hi->A));
-        const V2 t = mv(ga, hi->d);
+    if (hh) {
+        const M2 ga = mneg(mm(mid.C, minv(hi.B)));
+        R.C = mm(ga, hi.C);
+        R.B = madd(R.B, mm(ga, hi.A));
+        const V2 t = mv(ga, hi.d);
         R.d.x += t.x; R.d.y += t.y;
     }
     return R;
+}
+
+__device__ __forceinline__ Row row_identity() {          // placeholder for an absent neighbour (never used in arithmetic)
+    return Row{M2{0, 0, 0, 0}, M2{1, 0, 0, 1}, M2{0, 0, 0, 0}, V2{0, 0}};
 }
 
 // row of the system at implicit level LVL (stride 2^LVL) centred at level-0 index i
@@ -112,11 +118,10 @@ struct RowAt {
     static __device__ __forceinline__ Row get(const SysArgs &S, int i) {
         constexpr int s = 1 << (LVL - 1);
         const Row mid = RowAt<SYS, LVL - 1>::get(S, i);
-        Row lo, hi;
         const bool hl = i - s >= 0, hh = i + s < S.n;
-        if (hl) lo = RowAt<SYS, LVL - 1>::get(S, i - s);
-        if (hh) hi = RowAt<SYS, LVL - 1>::get(S, i + s);
-        return cr_reduce(hl ? &lo : nullptr, mid, hh ? &hi : nullptr);
+        const Row lo = hl ? RowAt<SYS, LVL - 1>::get(S, i - s) : row_identity();
+        const Row hi = hh ? RowAt<SYS, LVL - 1>::get(S, i + s) : row_identity();
+        return cr_reduce(hl, lo, mid, hh, hi);
     }
 };
 template <int SYS>
@@ -169,11 +174,11 @@ __device__ void cr_solve(const SysArgs &S, int lvl, double *lds, double *x0, dou
         // row m is written by its owner only and rows m +- s are not touched at this level, so
         // the update is done in place without a barrier between loads and stores
         for (int m = tid * 2 * s; m < nr; m += T1 * 2 * s) {
-            Row mid = Q.load(m), lo, hi;
+            const Row mid = Q.load(m);
             const bool hl = m - s >= 0, hh = m + s < nr;
-            if (hl) lo = Q.load(m - s);
-            if (hh) hi = Q.load(m + s);
-            Q.store(m, cr_reduce(hl ? &lo : nullptr, mid, hh ? &hi : nullptr));
+            const Row lo = hl ? Q.load(m - s) : row_identity();
+            const Row hi = hh ? Q.load(m + s) : row_identity();
+            Q.store(m, cr_reduce(hl, lo, mid, hh, hi));
         }
         __syncthreads();
     }
