@@ -135,8 +135,17 @@ class DryEngine:
         pass
 
 
+RESULT_OUT = None      # the process's real stdout, kept for the one JSON line (see main)
+
+
 def main():
+    global RESULT_OUT
     a = parse()
+    # stdout carries exactly one line, the JSON result: libraries that print banners on file descriptor 1 (RCCL
+    # prints its version block there when a communicator is created) are sent to stderr instead
+    sys.stdout.flush()
+    RESULT_OUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -385,7 +394,7 @@ def run(a, world, rank, local, dist):
             "source_hash": (None if a.dry_run else source_hash()),
         }
         out.update(extra)
-        print(json.dumps(out))
+        print(json.dumps(out), file=RESULT_OUT, flush=True)
         sys.stdout.flush()
     if comm is not None:
         comm.close()

@@ -12,6 +12,7 @@ Tolerances as in test_gpu_2d.py: SOLVE 1e-9 after linear solves / short marches,
 """
 import contextlib
 import io
+import os
 
 import numpy as np
 import pytest
@@ -453,3 +454,21 @@ def test_cost_collective_through_the_c_abi(V, O2):
         comm.close()
         for e in engs:
             e.close()
+
+
+def test_bench_prints_exactly_one_json_line():
+    """bench.py end to end on the card at a small size (child process, C-ABI collective, roofline leg): stdout carries
+    the JSON line and nothing else -- RCCL's version banner and anything else libraries print go to stderr."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--grid", "64", "--time-steps", "20", "--batch-per-gpu", "2",
+                        "--contexts", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1, r.stdout[:2000]
+    out = json.loads(lines[0])
+    assert out["config"]["collective"] == "cabi-rccl" and out["n_gpus"] == 1 and out["steps"] == 2
+    assert out["value"] > 0 and out["roofline"] is not None and 0 < out["roofline"]["frac"] < 1
