@@ -8,6 +8,7 @@
 #include "vch_gemm.h"
 #include "vch_fft.h"
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 
 thread_local char g_vch_err[512] = "";
@@ -49,6 +50,11 @@ struct vch2d_ctx {
     double *wts_mass, *W_cost;            // single planes
     double *part;                         // [B][nblk][NPART]
     TrajState *st, *st_host;
+    // look at the device state without a copy command and a stream wait: a one-workgroup kernel writes the records into
+    // mapped host memory (st_pub) and then a sequence number (seq_pub) the host spins on (sync_state)
+    TrajState *st_pub;
+    unsigned long long *seq_pub, seq_next;
+    bool look_spin;
     int *frozen_dev;                      // [B] line-search flags for k_set_frozen
     double *hist_dev, *hist_host;         // [B][HIST_CAP]
     // DCT-I matrices and eigenvalues
@@ -191,10 +197,44 @@ static int ensure_hist(vch2d_ctx *c, double **p) {
 }
 static inline long hist_stride(const vch2d_ctx *c) { return (long)(c->Mmax + 1) * c->G.plane; }
 
-static int sync_state(vch2d_ctx *c) {
+// records -> mapped host memory, then the sequence number (system-scope release after a system fence)
+__global__ void k_publish_state(const unsigned *__restrict__ st, int nwords, unsigned *__restrict__ dst,
+                                unsigned long long *seq, unsigned long long val) {
+    for (int i = threadIdx.x; i < nwords; i += blockDim.x) dst[i] = st[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(seq, val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// One look of the host at the per-trajectory state machine.  full = false (the per-step looks of a march): the stream is
+// NOT drained by a host wait -- the state arrives in mapped host memory behind everything enqueued so far and the host
+// polls for it (a copy command + hipStreamSynchronize cost ~35 us of idle device per look, this path ~10).  full = true,
+// or VCH_LOOK_SPIN=0: copy command and stream synchronisation (callers that go on to read other results or event times).
+static int sync_state(vch2d_ctx *c, bool full = true) {
     c->n_sync++;
-    HIPCHK(hipMemcpyAsync(c->st_host, c->st, sizeof(TrajState) * c->B, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    if (full || !c->look_spin) {
+        HIPCHK(hipMemcpyAsync(c->st_host, c->st, sizeof(TrajState) * c->B, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        return 0;
+    }
+    const unsigned long long want = ++c->seq_next;
+    static_assert(sizeof(TrajState) % 4 == 0, "TrajState is copied in 32-bit words");
+    hipLaunchKernelGGL(k_publish_state, dim3(1), dim3(256), 0, c->stream, (const unsigned *)c->st,
+                       (int)(sizeof(TrajState) / 4 * c->B), (unsigned *)c->st_pub, c->seq_pub, want);
+    HIPCHK(hipGetLastError());
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 1; __atomic_load_n(c->seq_pub, __ATOMIC_ACQUIRE) != want; ++spins) {
+        __builtin_ia32_pause();
+        if ((spins & 0x3fff) == 0) {
+            const hipError_t q = hipStreamQuery(c->stream);
+            if (q != hipSuccess && q != hipErrorNotReady) return vch_fail(VCH_ERR_HIP, "sync_state: %s", hipGetErrorString(q));
+            if (q == hipSuccess && __atomic_load_n(c->seq_pub, __ATOMIC_ACQUIRE) != want)
+                return vch_fail(VCH_ERR_STATE, "sync_state: stream drained but the state was not published");
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120))
+                return vch_fail(VCH_ERR_STATE, "sync_state: no state from the device after 120 s");
+        }
+    }
+    memcpy(c->st_host, c->st_pub, sizeof(TrajState) * c->B);
     return 0;
 }
 
@@ -299,6 +339,12 @@ extern "C" vch2d_ctx *vch2d_create(const vch2d_params *p, int batch, int max_ste
     hipMemsetAsync(c->st, 0, sizeof(TrajState) * batch, c->stream);
     if (hipMalloc((void **)&c->frozen_dev, sizeof(int) * batch) != hipSuccess) return fail("hipMalloc");
     if (hipHostMalloc((void **)&c->st_host, sizeof(TrajState) * batch) != hipSuccess) return fail("hipHostMalloc");
+    if (hipHostMalloc((void **)&c->st_pub, sizeof(TrajState) * batch, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostMalloc((void **)&c->seq_pub, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess)
+        return fail("hipHostMalloc (mapped)");
+    *c->seq_pub = 0;
+    c->seq_next = 0;
+    c->look_spin = !(getenv("VCH_LOOK_SPIN") && atoi(getenv("VCH_LOOK_SPIN")) == 0);
     if (hipHostMalloc((void **)&c->hist_host, sizeof(double) * batch * HIST_CAP) != hipSuccess) return fail("hipHostMalloc");
     c->phi_hist = c->u_hist = c->u_trial = c->phi_trial = c->phiQ = c->r_hist = c->p_hist = c->q_hist = nullptr;
     c->cost_part = c->cost_lvl = nullptr;
@@ -392,6 +438,8 @@ extern "C" void vch2d_destroy(vch2d_ctx *c) {
     if (c->tw_f) hipFree(c->tw_f);
     if (c->tw_s) hipFree(c->tw_s);
     hipHostFree(c->st_host);
+    hipHostFree(c->st_pub);
+    hipHostFree(c->seq_pub);
     hipHostFree(c->hist_host);
     hipHostFree(c->J_ring_host);
     hipFree(c->J_ring_dev);
@@ -588,7 +636,7 @@ static int schur_solve(vch2d_ctx *c, double dt, int budget, bool look) {
         }
         if (done < budget) {
             LAUNCH(k_cg_publish, dim3((c->B + 63) / 64), dim3(64), c->st, (done - 1) & 1, c->B);
-            VCHCHK(sync_state(c));
+            VCHCHK(sync_state(c, false));
             if (!any_lin_active(c)) break;
         }
     }
@@ -657,7 +705,7 @@ static int newton_level(vch2d_ctx *c, double dt, const double *un, const double 
             RESIDUAL_TRIAL();
         }
     }
-    VCHCHK(sync_state(c));
+    VCHCHK(sync_state(c, false));
     auto any_active = [&]() {
         for (int b = 0; b < c->B; ++b)
             if (c->st_host[b].newton_active) return true;
@@ -676,7 +724,7 @@ static int newton_level(vch2d_ctx *c, double dt, const double *un, const double 
         int tguard = 0;
         do {
             RESIDUAL_TRIAL();
-            VCHCHK(sync_state(c));
+            VCHCHK(sync_state(c, false));
             if (++tguard > ARMIJO_TRIALS + 2) return vch_fail(VCH_ERR_STATE, "newton_level: Armijo loop did not terminate");
         } while (any_trial());
     }
@@ -917,7 +965,7 @@ static int adjoint_solve_cg(vch2d_ctx *c, double dt, int budget, bool look) {
             }
             if (done < budget) {
                 LAUNCH(k_cg_publish, dim3((c->B + 63) / 64), dim3(64), c->st, (done - 1) & 1, c->B);
-                VCHCHK(sync_state(c));
+                VCHCHK(sync_state(c, false));
                 if (!any_lin_active(c)) break;
             }
         }
@@ -944,7 +992,7 @@ static int adjoint_solve_cg(vch2d_ctx *c, double dt, int budget, bool look) {
             LAUNCH(k_fin_cg_beta, dim3(c->B), dim3(64), c->st, c->part, c->nblk, 1, c->lin_tol, c->lin_maxit, 0);
         }
         if (done < budget && look) {
-            VCHCHK(sync_state(c));
+            VCHCHK(sync_state(c, false));
             if (!any_lin_active(c)) break;
         }
     }
@@ -1124,7 +1172,7 @@ static int backward_pass(vch2d_ctx *c, const double *phi_hist_dev, int M, const 
                phiQ_dev ? phiQ_dev + (long)(n + 1) * G.plane : (const double *)nullptr, hs, dtn, b1, rhs, Dn, c->part);
         LAUNCH(k_fin_lin_begin, dim3(c->B), dim3(64), c->st, c->part, c->nblk, 0, c->P.tau, c->P.kappa, dtn, c->lin_tol);
         if (safe || steps_since_look >= ADJ_LOOK || sweeps < 0) {
-            VCHCHK(sync_state(c));
+            VCHCHK(sync_state(c, false));
             steps_since_look = 0;
             int longest = 0;
             for (int b = 0; b < c->B; ++b) longest = std::max(longest, c->st_host[b].step_lin_max);

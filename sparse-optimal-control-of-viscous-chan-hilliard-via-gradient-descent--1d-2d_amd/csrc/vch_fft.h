@@ -47,6 +47,31 @@ __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
     return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
+#ifndef FFT_RCP
+#define FFT_RCP 1             // spectral multiplier of a column pair from ONE v_rcp_f64 of the product of the two
+                              // denominators + two Newton steps instead of two IEEE divisions
+#endif
+// scale * (mult_m ? m : 1) / (c0 + m (c1 + c2 m)) for the two columns of a pair.  The denominators are positive and of
+// moderate magnitude (1/dt ... c2 m^2), so the operand scaling and fix-up of an IEEE division buy nothing: one hardware
+// reciprocal of pa*pb refined by two Newton steps, then 1/pa = r pb, 1/pb = r pa (within 2 ulp of the divisions).
+struct SpecArgs;
+template <class SP>
+__device__ __forceinline__ void spec_mult2(const SP &sp, double c1, double scale, double ma, double mb, double &fa, double &fb) {
+    const double pa = sp.c0 + ma * (c1 + sp.c2 * ma), pb = sp.c0 + mb * (c1 + sp.c2 * mb);
+    const double na = scale * (sp.mult_m ? ma : 1.0), nb = scale * (sp.mult_m ? mb : 1.0);
+#if FFT_RCP
+    const double d = pa * pb;
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    fa = na * (r * pb);
+    fb = nb * (r * pa);
+#else
+    fa = na / pa;
+    fb = nb / pb;
+#endif
+}
+
 // LDS image addressing.  A wavefront's ds_*_b128 is served 8 lanes (one 128-byte row of banks) per clock.
 // Reads of every pass take consecutive complex numbers (conflict-free); the Stockham writes of the first two
 // radix-4 passes do not: lane j writes index 4j + r (pass 0: 8 lanes fall on 2 of the 8 slots of a row) and
@@ -77,6 +102,10 @@ __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
 #endif
 #ifndef FFT_COLS_PAIR
 #define FFT_COLS_PAIR 1       // column pass: 16-byte accesses of a column pair (-1.3 % on the march, r02_fft_variants.txt)
+#endif
+#ifndef FFT_COLS_FUSE
+#define FFT_COLS_FUSE 1       // column pass: the last pass of the first transform hands its outputs to the first pass of the
+                              // second in registers (same eight indices per thread), multiplier applied on the way
 #endif
 #ifndef CG_ROWS_STAGED
 #define CG_ROWS_STAGED 1      // first pass of a CG sweep: visit every node once and stage the even extension in LDS (0: feed the
@@ -245,8 +274,19 @@ __device__ __forceinline__ void fft1024_wave(double2 *buf, const FftAxis ax, Emi
     }
 }
 
-template <int C, int LOGL, class Emit = FftNoEmit, class Ingest = FftNoIngest>
-__device__ __forceinline__ void fft_lds(double2 *buf, const FftAxis ax, Emit emit = Emit(), Ingest ingest = Ingest()) {
+// REGMODE (two transforms back to back, k_dct_cols): 1 = the last pass leaves its outputs in xr[0..8) instead of the image,
+// 2 = the first pass takes its inputs from xr.  With one butterfly octet per thread the first radix-8 pass reads the
+// indices j + s L/8 (s = 0..7) of its transform, and the last pass of the plan produces exactly those: a radix-8 pass
+// with Ns = L/8 writes j + r L/8, a radix-4 pass with Ns = L/4 and two butterflies (j, j + L/8) per thread writes
+// j + (i + 2 r) L/8.  FftRegOk says for which images that holds.
+template <int C, int LOGL>
+struct FftRegOk {
+    static constexpr bool V = FFT_R8 && !FFT_W64 && (LOGL == 9 || ((LOGL == 10 || LOGL == 11) && C == (1 << LOGL)));
+};
+template <int C, int LOGL, class Emit = FftNoEmit, class Ingest = FftNoIngest, int REGMODE = 0>
+__device__ __forceinline__ void fft_lds(double2 *buf, const FftAxis ax, Emit emit = Emit(), Ingest ingest = Ingest(),
+                                        double2 *xr = nullptr) {
+    static_assert(REGMODE == 0 || FftRegOk<C, LOGL>::V, "register hand-over needs a compile-time radix-8 plan");
     constexpr bool EMIT = Emit::ACTIVE && LOGL >= 9 && LOGL <= 11 && FFT_R8;
     constexpr bool INGEST = Ingest::ACTIVE && LOGL >= 9 && LOGL <= 11 && FFT_R8;
     constexpr int T = FftThreads<C, LOGL>::T;
@@ -272,8 +312,10 @@ __device__ __forceinline__ void fft_lds(double2 *buf, const FftAxis ax, Emit emi
             const int lNs = 3 * ps, Ns = 1 << lNs, k = j & (Ns - 1);
             double2 a[8];
 #pragma unroll
-            for (int r = 0; r < 8; ++r)
-                a[r] = (INGEST && ps == 0) ? ingest(fb + j + r * (L >> 3)) : buf[swz<LOGL>(fb + j + r * (L >> 3))];
+            for (int r = 0; r < 8; ++r) {
+                if (REGMODE == 2 && ps == 0) a[r] = xr[r];
+                else a[r] = (INGEST && ps == 0) ? ingest(fb + j + r * (L >> 3)) : buf[swz<LOGL>(fb + j + r * (L >> 3))];
+            }
             if (ps) {                                   // inputs r = 1..7 times w^r, w = exp(-2 pi i k / (8 Ns))
                 const double2 w1 = ax.tw[k << (logL - 3 - lNs)];
                 double2 w = w1;
@@ -307,7 +349,10 @@ __device__ __forceinline__ void fft_lds(double2 *buf, const FftAxis ax, Emit emi
                 o[h + 6] = make_double2(t1.x - t3.x, t1.y - t3.y);
             }
             const int wb = fb + ((j >> lNs) << (lNs + 3)) + k;
-            if (EMIT && 3 * (ps + 1) == LOGL) {          // last pass of the 8x8x8 plan
+            if (REGMODE == 1 && 3 * (ps + 1) == LOGL) {  // last pass of the 8x8x8 plan, outputs stay with the thread
+#pragma unroll
+                for (int r = 0; r < 8; ++r) xr[r] = o[r];
+            } else if (EMIT && 3 * (ps + 1) == LOGL) {   // last pass of the 8x8x8 plan
                 if (Emit::TO_LDS) __syncthreads();
 #pragma unroll
                 for (int r = 0; r < 8; ++r) emit(wb + r * Ns, o[r]);
@@ -366,7 +411,13 @@ __device__ __forceinline__ void fft_lds(double2 *buf, const FftAxis ax, Emit emi
             v[i][3] = make_double2(t1.x - t3.x, t1.y - t3.y);
             wbase[i] = f * L + ((j >> logNs) << (logNs + 2)) + k;
         }
-        if (EMIT && logNs + 2 == logL) {
+        if (REGMODE == 1 && logNs + 2 == logL) {
+            static_assert(REGMODE != 1 || LOGL == 9 || NB4 == 2, "two radix-4 butterflies per thread");
+#pragma unroll
+            for (int i = 0; i < NB4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xr[(i + 2 * r) & 7] = v[i][r];
+        } else if (EMIT && logNs + 2 == logL) {
             if (Emit::TO_LDS) __syncthreads();
 #pragma unroll
             for (int i = 0; i < NB4; ++i)
@@ -1194,12 +1245,33 @@ __global__ __launch_bounds__((FftThreads<C, LOGL>::T)) void k_dct_cols(Geom G, F
             const int ca = col0_ + 2 * f, cb = ca + 1;
             const double msk = sp_.ms[ks];
             const double ma = msk + sp_.mf[ca < nf_ ? ca : nf_ - 1], mb = msk + sp_.mf[cb < nf_ ? cb : nf_ - 1];
-            v.x *= scale_ * (sp_.mult_m ? ma : 1.0) / (sp_.c0 + ma * (c1_ + sp_.c2 * ma));
-            v.y *= scale_ * (sp_.mult_m ? mb : 1.0) / (sp_.c0 + mb * (c1_ + sp_.c2 * mb));
+            double fa, fb;
+            spec_mult2(sp_, c1_, scale_, ma, mb, fa, fb);
+            v.x *= fa;
+            v.y *= fb;
             buf_[swz<LOGL>(idx)] = v;
         }
     };
-    if (DIRECT && (FFT_COLS_EMIT & 1)) {
+    constexpr bool FUSE = FFT_COLS_FUSE && DIRECT && FftRegOk<C, LOGL>::V && !FFT_COLS_INGEST && !(FFT_COLS_EMIT & 2);
+    if constexpr (FUSE) {
+        // first transform, its last pass kept in registers; multiplier; second transform fed from those registers: one
+        // LDS round trip and one barrier pair less than ScaleEmit, same arithmetic
+        double2 xr[8];
+        fft_lds<C, LOGL, FftNoEmit, FftNoIngest, 1>(buf, ax, FftNoEmit(), FftNoIngest(), xr);
+        const int f = tid >> (LG - 3), j = tid & ((LL >> 3) - 1);
+        const int ca = col0 + 2 * f, cb = ca + 1;
+        const double mfa = sp.mf[ca < G.nf ? ca : G.nf - 1], mfb = sp.mf[cb < G.nf ? cb : G.nf - 1];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int k = j + s * (LL >> 3), ks = k <= LL / 2 ? k : LL - k;
+            const double msk = sp.ms[ks];
+            double fa, fb;
+            spec_mult2(sp, c1, scale, msk + mfa, msk + mfb, fa, fb);
+            xr[s].x *= fa;
+            xr[s].y *= fb;
+        }
+        fft_lds<C, LOGL, FftNoEmit, FftNoIngest, 2>(buf, ax, FftNoEmit(), FftNoIngest(), xr);
+    } else if (DIRECT && (FFT_COLS_EMIT & 1)) {
         if (FFT_COLS_INGEST)
             fft_lds<C, LOGL>(buf, ax, ScaleEmit{buf, sp, c1, scale, col0, G.nf}, ColIngest{ib, (long)G.pitch, col0, G.nf});
         else
@@ -1213,8 +1285,10 @@ __global__ __launch_bounds__((FftThreads<C, LOGL>::T)) void k_dct_cols(Geom G, F
             const double msk = sp.ms[ks];
             double2 v = buf[swz<LOGL>(idx)];
             double ma = msk + sp.mf[ca < G.nf ? ca : G.nf - 1], mb = msk + sp.mf[cb < G.nf ? cb : G.nf - 1];
-            v.x *= scale * (sp.mult_m ? ma : 1.0) / (sp.c0 + ma * (c1 + sp.c2 * ma));
-            v.y *= scale * (sp.mult_m ? mb : 1.0) / (sp.c0 + mb * (c1 + sp.c2 * mb));
+            double fa, fb;
+            spec_mult2(sp, c1, scale, ma, mb, fa, fb);
+            v.x *= fa;
+            v.y *= fb;
             buf[swz<LOGL>(idx)] = v;
         }
         __syncthreads();
@@ -1239,7 +1313,7 @@ __global__ __launch_bounds__((FftThreads<C, LOGL>::T)) void k_dct_cols(Geom G, F
         fft_lds<C, LOGL>(buf, ax, ColEmit{ob, (long)G.pitch, col0, G.nf});
         return;
     }
-    fft_lds<C, LOGL>(buf, ax);
+    if constexpr (!FUSE) fft_lds<C, LOGL>(buf, ax);
 #if FFT_COLS_PAIR
     for (int idx = tid; idx < n1 * nfft; idx += T) {
         const int r = nfft == 1 ? idx : idx / nfft, f = nfft == 1 ? 0 : idx - r * nfft;
