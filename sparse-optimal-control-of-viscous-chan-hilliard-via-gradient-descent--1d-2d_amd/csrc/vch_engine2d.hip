@@ -42,6 +42,14 @@ struct vch2d_ctx {
     double *cg_z2;                        // second residual buffer of the forward CG (z ping-pongs r <-> cg_z2)
     double *xf;                           // finished dphi of a Newton solve (written by the back-substitution kernel)
     int cg_last;                          // index of the last sweep schur_solve enqueued (-1: none), for dmu_ceiling()
+    // starting guess of a step's first Newton solve (k_guess): first increments of the two previous steps (ring, written by
+    // k_dmu_ceiling_fin), the guess itself, its coefficients for the step being enqueued (0, 0 = no guess) and the ring
+    // slot this step's increment goes to
+    double *dprev[GUESS_RING], *x0g;
+    bool guess_on;
+    double guess_c[GUESS_ORD];            // coefficients of d_{n-1} .. d_{n-GUESS_ORD} (all 0: no guess this step)
+    int guess_wr, guess_step;             // ring slot of this step's increment (-1: not kept); step index within the march
+    int guess_order, guess_max;           // increments the extrapolation uses (adapted from the ratio the last guess achieved)
     double *gpart2;                       // second half of gpart
     double *gpart3;                       // [2][B][gnblk + ns] partials of <z',z'>_Z of the stencil-free sweep
     double *gpart;                        // [B][gnblk] partials written by the GEMM epilogue
@@ -320,7 +328,7 @@ extern "C" vch2d_ctx *vch2d_create(const vch2d_params *p, int batch, int max_ste
     for (auto q : two)
         if (dalloc(q, 2 * bp, c->stream)) return fail("hipMalloc");
     double **one[] = {&c->w, &c->wnew, &c->mu0, &c->cphi, &c->cmu, &c->x, &c->r, &c->dmu, &c->t1, &c->t2,
-                      &c->cg_p[0], &c->cg_p[1], &c->cg_v, &c->cg_q, &c->cg_z2, &c->xf, &c->tmp[0], &c->tmp[1], &c->tmp[2], &c->tmp[3], &c->tmp[4], &c->tmp[5], &c->phiT, &c->phi0};
+                      &c->cg_p[0], &c->cg_p[1], &c->cg_v, &c->cg_q, &c->cg_z2, &c->xf, &c->dprev[0], &c->dprev[1], &c->dprev[2], &c->dprev[3], &c->dprev[4], &c->dprev[5], &c->dprev[6], &c->dprev[7], &c->x0g, &c->tmp[0], &c->tmp[1], &c->tmp[2], &c->tmp[3], &c->tmp[4], &c->tmp[5], &c->phiT, &c->phi0};
     for (auto q : one)
         if (dalloc(q, bp, c->stream)) return fail("hipMalloc");
     if (dalloc(&c->wts_mass, G.plane, c->stream) || dalloc(&c->W_cost, G.plane, c->stream)) return fail("hipMalloc");
@@ -416,6 +424,14 @@ extern "C" vch2d_ctx *vch2d_create(const vch2d_params *p, int batch, int max_ste
             }
         }
     }
+    // starting guess of a step's first Newton solve (k_guess): stencil-free sweep only; VCH_GUESS=0 turns it off
+    c->guess_on = c->use_fft && !c->half_f && !c->half_s && !(getenv("VCH_GUESS") && atoi(getenv("VCH_GUESS")) == 0);
+    for (double &g : c->guess_c) g = 0.0;
+    c->guess_wr = -1;
+    c->guess_step = 0;
+    c->guess_order = 1;
+    c->guess_max = GUESS_ORD;
+    if (const char *e = getenv("VCH_GUESS_MAX")) c->guess_max = std::max(1, std::min(GUESS_ORD, atoi(e)));
     if (hipStreamSynchronize(c->stream) != hipSuccess) return fail("hipStreamSynchronize");
     return c;
 }
@@ -425,7 +441,7 @@ extern "C" void vch2d_destroy(vch2d_ctx *c) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     double *all[] = {c->phi_s, c->mu_s, c->Rphi_s, c->rhs_s, c->D_s, c->w, c->wnew, c->mu0, c->cphi, c->cmu, c->x,
-                     c->r, c->dmu, c->t1, c->t2, c->cg_p[0], c->cg_p[1], c->cg_v, c->cg_q, c->cg_z2, c->xf, c->gpart, c->gpart3, c->tmp[0], c->tmp[1], c->tmp[2], c->tmp[3], c->tmp[4], c->tmp[5],
+                     c->r, c->dmu, c->t1, c->t2, c->cg_p[0], c->cg_p[1], c->cg_v, c->cg_q, c->cg_z2, c->xf, c->dprev[0], c->dprev[1], c->dprev[2], c->dprev[3], c->dprev[4], c->dprev[5], c->dprev[6], c->dprev[7], c->x0g, c->gpart, c->gpart3, c->tmp[0], c->tmp[1], c->tmp[2], c->tmp[3], c->tmp[4], c->tmp[5],
                      c->phiT, c->phi0, c->wts_mass, c->W_cost, c->part, c->hist_dev, c->alpha_dev, c->J_dev, c->Q1f,
                      c->Q2f, c->Q1s, c->Q2s, c->mf, c->ms, c->phi_hist, c->u_hist, c->u_trial, c->phi_trial, c->phiQ,
                      c->r_hist, c->p_hist, c->q_hist, c->cost_part, c->cost_lvl, c->tfrac_dev};
@@ -602,7 +618,7 @@ static int schur_solve(vch2d_ctx *c, double dt, int budget, bool look) {
                 // sweep `done`: the reduction point of sweep done-1 is resolved inside the first kernel and its step goes
                 // into x and z on the way into the row transform; 3 launches per sweep, no stencil
                 CgSweepArgs a{done == 0 ? zb[0] : zb[(done + 1) & 1], c->cg_q, po, c->x, zb[done & 1], pn, c->D_s, c->slot_stride,
-                              c->gpart, c->gpart2, c->gpart3, done, c->lin_maxit, c->B};
+                              c->gpart, c->gpart2, c->gpart3, done, c->lin_maxit, c->B, c->x0g};
 #define CG_ROWS(FIRST_, C_, LG_)                                                                                          \
     do {                                                                                                                  \
         const int rpw = 2 * (C_ >> c->fax.logL);                                                                          \
@@ -659,7 +675,8 @@ static int dmu_ceiling(vch2d_ctx *c, int strict) {
         FinSolveArgs f{c->gpart, c->gpart2, c->gpart3 + (size_t)rd * c->B * c->gnblk, c->gnblk, last >= 1 ? 1 : 0, rd, c->lin_maxit,
                        c->cg_p[last & 1]};
         LAUNCH(k_dmu_ceiling_fin, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, (const double *)c->x, f, (const double *)c->phi_s,
-               (const double *)c->D_s, (const double *)c->Rphi_s, c->dmu, c->xf, c->part);
+               (const double *)c->D_s, (const double *)c->Rphi_s, c->dmu, c->xf, c->part,
+               c->guess_wr >= 0 ? c->dprev[c->guess_wr] : (double *)nullptr);
         LAUNCH(k_fin_ceiling, dim3(c->B), dim3(64), c->st, c->part, c->nblk, strict, rd ^ 1);
     } else {
         LAUNCH(k_dmu_ceiling, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->x, c->phi_s, c->D_s, c->Rphi_s, c->dmu, c->xf,
@@ -675,7 +692,7 @@ static int dmu_ceiling(vch2d_ctx *c, int strict) {
         LAUNCHC(PC_RESIDUAL, (k_residual<1>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s,     \
                 c->Rphi_s, c->rhs_s, c->D_s, c->mu0, c->xf, c->dmu, c->cphi, c->cmu, dt, c->part);                          \
         LAUNCH((k_fin_residual<1>), dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->hist_dev, c->P.kappa, dt, c->lin_tol, \
-               eta_);                                                                                                      \
+               eta_, 0);                                                                                                   \
     } while (0)
 
 // One implicit time level for the whole batch (F2:323-427).  On entry the old level is
@@ -697,7 +714,19 @@ static int newton_level(vch2d_ctx *c, double dt, const double *un, const double 
     LAUNCH(k_fin_newton_begin, dim3(c->B), dim3(64), c->st);
     LAUNCHC(PC_RESIDUAL, (k_residual<0>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s, c->Rphi_s, c->rhs_s,
            c->D_s, c->mu0, c->x, c->dmu, c->cphi, c->cmu, dt, c->part);
-    LAUNCH((k_fin_residual<0>), dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->hist_dev, c->P.kappa, dt, c->lin_tol, eta_);
+    // starting guess of the first solve (marches on the stencil-free path only; forward_core sets the coefficients)
+    const bool guess = in_march && c->guess_on && c->guess_c[0] != 0.0;
+    if (guess) {
+        GuessArgs ga;
+        for (int j = 0; j < GUESS_ORD; ++j) {
+            ga.d[j] = c->dprev[(c->guess_step - 1 - j) & (GUESS_RING - 1)];
+            ga.c[j] = c->guess_c[j];
+        }
+        LAUNCH(k_guess, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, ga, (const double *)c->D_s, dt, c->rhs_s, c->x0g,
+               c->part);
+    }
+    LAUNCH((k_fin_residual<0>), dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->hist_dev, c->P.kappa, dt, c->lin_tol, eta_,
+           guess ? 1 : 0);
     if (c->spec) {
         for (int s = 0; s < c->spec_slots; ++s) {
             VCHCHK(schur_solve(c, dt, c->spec_cgb[s], false));
@@ -716,6 +745,12 @@ static int newton_level(vch2d_ctx *c, double dt, const double *un, const double 
             if (c->st_host[b].newton_active && c->st_host[b].need_trial) return true;
         return false;
     };
+    if (getenv("VCH_DEBUG_GUESS")) {
+        const TrajState &S = c->st_host[0];
+        fprintf(stderr, "guess order %d c %.1f %.1f %.1f %.1f | traj 0: ratio %.3e solves %d sweeps %d %d %d normR %.3e active %d\n",
+                c->guess_order, c->guess_c[0], c->guess_c[1], c->guess_c[2], c->guess_c[3], S.guess_ratio, S.step_solves, S.step_lin[0],
+                S.step_lin[1], S.step_lin[2], S.normR, S.newton_active);
+    }
     int guard = 0;
     while (any_active()) {
         if (++guard > NEWTON_MAXIT + 2) return vch_fail(VCH_ERR_STATE, "newton_level: state machine did not terminate");
@@ -1082,11 +1117,37 @@ static int forward_core(vch2d_ctx *c, const double *u_dev, int u_rows, const dou
     LAUNCH(k_mass, c->grid, dim3(NTH), c->G, c->st, c->slot_stride, c->phi_s, c->wts_mass, 0, c->part);
     LAUNCH(k_fin_mass, dim3(c->B), dim3(64), c->st, c->part, c->nblk, 1);
     if (hist_out) LAUNCH(k_copy_plane, c->grid, dim3(NTH), c->G, c->phi_s, c->G.plane, hist_out, hs);
+    c->guess_order = 1;
     for (int step = 0; step < M; ++step) {
         const double *un = nullptr, *unp1 = nullptr;
         if (u_dev && step < u_rows - 1) {        // F2:545-548
             un = u_dev + (long)step * c->G.plane;
             unp1 = u_dev + (long)(step + 1) * c->G.plane;
+        }
+        // guess for the step's first Newton solve (k_guess): the increment rate d_k / dt_k, taken at the step midpoints, is
+        // extrapolated to this step's midpoint by the polynomial through the last `order` steps; this step's increment
+        // replaces the oldest one in the ring
+        for (double &g : c->guess_c) g = 0.0;
+        c->guess_wr = -1;
+        c->guess_step = step;
+        if (c->guess_on) {
+            c->guess_wr = step & (GUESS_RING - 1);
+            const int m = std::min(std::min(step, c->guess_order), c->guess_max);
+            if (m >= 1) {
+                double mid[GUESS_ORD + 1];                    // midpoints of steps n, n-1, .. n-m relative to the start of step n
+                mid[0] = 0.5 * dt[step];
+                double t0 = 0.0;
+                for (int j = 1; j <= m; ++j) {
+                    t0 -= dt[step - j];
+                    mid[j] = t0 + 0.5 * dt[step - j];
+                }
+                for (int j = 1; j <= m; ++j) {       // Lagrange weight of node j at mid[0]
+                    double w = 1.0;
+                    for (int k = 1; k <= m; ++k)
+                        if (k != j) w *= (mid[0] - mid[k]) / (mid[j] - mid[k]);
+                    c->guess_c[j - 1] = w * dt[step] / dt[step - j];
+                }
+            }
         }
         VCHCHK(newton_level(c, dt[step], un, unp1, hs, nullptr, true));
         // clip, mass fix, store (F2:562-585)
@@ -1094,7 +1155,26 @@ static int forward_core(vch2d_ctx *c, const double *u_dev, int u_rows, const dou
         LAUNCH(k_post, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s,
                hist_out ? hist_out + (long)(step + 1) * c->G.plane : (double *)nullptr, hs, (const double *)c->part);
         std::swap(c->w, c->wnew);
+        if (c->guess_on && c->guess_c[0] != 0.0) {
+            // order for the next step from what this guess achieved (worst trajectory that solved): one more increment
+            // while the deflated right-hand side keeps shrinking, one less when the guess did not pay (the transient of
+            // the first steps, a kink of the control in time)
+            double worst = 0.0;
+            bool any = false;
+            for (int b = 0; b < c->B; ++b) {
+                const TrajState &S = c->st_host[b];
+                if (S.frozen || S.step_solves < 1) continue;
+                any = true;
+                worst = std::max(worst, std::isfinite(S.guess_ratio) ? S.guess_ratio : 1e300);
+            }
+            if (any) {
+                if (worst < 0.25) c->guess_order = std::min(c->guess_order + 1, GUESS_ORD);
+                else if (worst > 0.7) c->guess_order = std::max(c->guess_order - 1, 1);
+            }
+        }
     }
+    for (double &g : c->guess_c) g = 0.0;
+    c->guess_wr = -1;
     return 0;
 }
 

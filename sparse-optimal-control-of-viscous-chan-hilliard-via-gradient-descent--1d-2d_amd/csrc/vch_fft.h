@@ -609,6 +609,7 @@ struct CgSweepArgs {
     const double *gpart, *gpart2;         // [B][gnblk] partials of <p,q>_Z, <q,q>_Z from the previous sweep's last pass
     double *gpart3;                       // [2][B][gnblk] partials of <z',z'>_Z, copy = sweep parity
     int it, maxit, nbatch;
+    const double *x0;                     // FIRST: starting guess of a primed solve (TrajState::x_primed), else unused
 };
 
 // the three sums of a reduction point by the waves of the workgroup (fixed order); s3 = LDS [3]
@@ -640,12 +641,14 @@ __global__ __launch_bounds__(NTH) void k_dmu_ceiling_fin(Geom G, Phys P, TrajSta
                                                          const double *__restrict__ x, FinSolveArgs f,
                                                          const double *__restrict__ phi_s, const double *__restrict__ D_s,
                                                          const double *__restrict__ Rphi_s, double *__restrict__ dmu,
-                                                         double *__restrict__ x_out, double *__restrict__ part) {
+                                                         double *__restrict__ x_out, double *__restrict__ part,
+                                                         double *__restrict__ x_keep) {
     TILE_COORDS;
     if (!st[b].newton_active || st[b].need_trial) return;
     __shared__ double sx[(TY + 2) * (TX + 2)];
     __shared__ double sred[NPART * 4];
     __shared__ double s3[3];
+    const bool keep = x_keep && st[b].iters == 1;       // the step's first Newton increment, for the next steps' k_guess
     constexpr int W = TX + 2;
     const long pb = b * G.plane;
     const int slot = st[b].slot;
@@ -673,6 +676,7 @@ __global__ __launch_bounds__(NTH) void k_dmu_ceiling_fin(Geom G, Phys P, TrajSta
             long o = pb + (long)r * G.pitch + c, os = slot * slot_stride + o;
             double d = sx[p];
             x_out[o] = d;
+            if (keep) x_keep[o] = d;
             dmu[o] = 2.0 * ((-0.5 * P.kappa * lap_at<W>(sx, p, G.ax, G.ay) + D_s[os] * d) + Rphi_s[os]);
             double ph = phi_s[os];
             if (d > 0.0) acc[0] = fmin(acc[0], (1.0 - DELTA_SEP - ph) / d);
@@ -752,6 +756,7 @@ __global__ __launch_bounds__((FftThreads<C, LOGL>::T)) void k_cg_rows_fwd(Geom G
     }
     const double dbar = st[b].dbar;
     const double *Dp = a.Dslot + st[b].slot * a.d_slot_stride + pb;
+    const bool primed = FIRST && a.x0 && st[b].x_primed;
     double acc = 0.0;
     // value fed into the transform at node (row, m); the OWNER visit (each node exactly once) also applies the step
     auto node = [&](int row, int m, bool owner) -> double {
@@ -762,7 +767,7 @@ __global__ __launch_bounds__((FftThreads<C, LOGL>::T)) void k_cg_rows_fwd(Geom G
         if (FIRST) {
             pn = a.z[pb + o];
             if (owner) {
-                a.x[pb + o] = 0.0;
+                a.x[pb + o] = primed ? a.x0[pb + o] : 0.0;
                 a.p_new[pb + o] = pn;
             }
         } else {

@@ -43,6 +43,11 @@ struct TrajState {
     // the Schur residual it leaves -- which is the nonlinear residual of the next iterate up to second-order terms --
     // is a small fraction of the Newton tolerance; lin_maxabs = worst (final relative residual x ||rhs||_2) of a solve
     double lin_reltol, lin_maxabs;
+    // starting guess of the step's first Newton solve (k_guess): the sweeps start from x = x0 instead of 0 and solve for the
+    // deflated right-hand side rhs - A x0; lin_rscale = ||rhs - A x0|| / ||rhs|| keeps lin_maxrel relative to ||rhs||
+    int x_primed, guess_pad;
+    double lin_rscale;
+    double guess_ratio;        // ||rhs - A x0|| / ||rhs|| of this step's guess (uncapped), for the host's choice of the order
     // per time step, for the host's launch schedule: linear solves started and the longest of them
     int step_solves, step_lin_max;
     int step_lin[4];           // sweeps of the first four solves of the step
@@ -375,6 +380,79 @@ __global__ __launch_bounds__(NTH) void k_schur(Geom G, Phys P, const TrajState *
             int p1 = (ly + 1) * W1 + lx + 1, p2 = (ly + 2) * W2 + lx + 2;
             out[pb + (long)r * G.pitch + c] = sx[p2] * idt - lap_at<W1>(stt, p1, G.ax, G.ay);
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Starting guess for the first Newton solve of a time step.  Along a march the first Newton increments d_n vary smoothly
+// from step to step: measured as the solver sees it, ||A (d_n - guess)|| / ||A d_n|| at 512^2, the previous increment
+// alone leaves 1e-2, linear extrapolation 1e-4, quadratic 3e-6 and cubic 1e-7 (scripts/r2_extrap.py; the first dozen
+// steps of the spinodal transient are the exception, there the order is kept low by the host, forward_core).  So the
+// solve starts from x0 = sum_j c_j d_{n-j} (up to GUESS_ORD previous increments, coefficients = polynomial extrapolation of
+// the increment rate over the step midpoints): this kernel, between k_residual<0> and k_fin_residual<0>, stores x0 and
+// deflates the right-hand side,
+//       rhs <- rhs - A x0        (A = the 13-point Schur operator of k_schur, D of the current iterate),
+// and replaces the partial of sum rhs^2 (slot 1; the old one moves to slot 4) so that the forcing rule of the solve
+// (newton_lin_tol) sees the deflated norm: the sweeps then reach the SAME absolute Schur residual target with fewer
+// sweeps.  The solve itself is unchanged -- its first sweep takes x = x0 instead of 0 (TrajState::x_primed).
+// Any x0 is valid; non-finite entries of a stale d plane are read as 0.
+// ---------------------------------------------------------------------------------
+constexpr int GUESS_RING = 8;     // increments kept (a power of two)
+constexpr int GUESS_ORD = 6;      // at most this many enter the extrapolation
+struct GuessArgs {
+    const double *d[GUESS_ORD];   // first Newton increments of steps n-1 .. n-GUESS_ORD, [B][plane]
+    double c[GUESS_ORD];          // their coefficients (0 = plane not used)
+};
+__global__ __launch_bounds__(NTH) void k_guess(Geom G, Phys P, const TrajState *__restrict__ st, long slot_stride,
+                                               GuessArgs ga, const double *__restrict__ D_s, double dt,
+                                               double *__restrict__ rhs_s, double *__restrict__ x0, double *__restrict__ part) {
+    TILE_COORDS;
+    const TrajState S = st[b];
+    if (!S.newton_active || !S.need_trial) return;
+    __shared__ double sx[(TY + 4) * (TX + 4)];
+    __shared__ double stt[(TY + 2) * (TX + 2)];
+    __shared__ double sred[4];
+    constexpr int W2 = TX + 4, W1 = TX + 2;
+    const long pb = b * G.plane;
+    for (int e = threadIdx.x; e < W2 * (TY + 4); e += NTH) {
+        int ly = e / W2, lxx = e - ly * W2;
+        int gr = refl(r0 - 2 + ly, G.ns), gc = refl(c0 - 2 + lxx, G.nf);
+        long o = pb + (long)gr * G.pitch + gc;
+        double v = ga.c[0] * ga.d[0][o];
+#pragma unroll
+        for (int j = 1; j < GUESS_ORD; ++j)
+            if (ga.c[j] != 0.0) v += ga.c[j] * ga.d[j][o];
+        sx[e] = isfinite(v) ? v : 0.0;
+    }
+    __syncthreads();
+    const double *Dp = D_s + S.slot * slot_stride + pb;
+    for (int e = threadIdx.x; e < (TY + 2) * W1; e += NTH) {
+        int ly = e / W1, lxx = e - ly * W1;
+        int gr = refl(r0 - 1 + ly, G.ns), gc = refl(c0 - 1 + lxx, G.nf);
+        int p2 = (ly + 1) * W2 + lxx + 1;
+        stt[e] = -0.5 * P.kappa * lap_at<W2>(sx, p2, G.ax, G.ay) + Dp[(long)gr * G.pitch + gc] * sx[p2];
+    }
+    __syncthreads();
+    const double idt = 1.0 / dt;
+    double acc = 0.0;
+    for (int k = 0; k < TY / 4; ++k) {
+        int ly = ly0 + 4 * k, r = r0 + ly, c = c0 + lx;
+        if (r < G.ns && c < G.nf) {
+            int p1 = (ly + 1) * W1 + lx + 1, p2 = (ly + 2) * W2 + lx + 2;
+            long o = pb + (long)r * G.pitch + c, os = S.slot * slot_stride + o;
+            const double rh = rhs_s[os] - (sx[p2] * idt - lap_at<W1>(stt, p1, G.ax, G.ay));
+            rhs_s[os] = rh;
+            x0[o] = sx[p2];
+            acc += rh * rh;
+        }
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double *pp = part + ((long)b * nblk + blk) * NPART;
+        pp[4] = pp[1];
+        pp[1] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
     }
 }
 
@@ -880,6 +958,9 @@ __global__ void k_fin_newton_begin(TrajState *st) {
     S.step_solves = 0;
     S.step_lin_max = 0;
     S.step_lin[0] = S.step_lin[1] = S.step_lin[2] = S.step_lin[3] = 0;
+    S.x_primed = 0;
+    S.lin_rscale = 1.0;
+    S.guess_ratio = 1.0;
 }
 
 // After k_residual: the Armijo test (F2:411-419) or the bookkeeping of the initial residual,
@@ -920,13 +1001,14 @@ __device__ __forceinline__ double newton_lin_tol(double r0, double lin_tol, doub
 
 template <int MODE>
 __global__ void k_fin_residual(TrajState *st, const double *__restrict__ part, int nblk,
-                               double *__restrict__ hist, double kappa, double dt, double lin_tol, double eta) {
+                               double *__restrict__ hist, double kappa, double dt, double lin_tol, double eta, int guess) {
     const int b = blockIdx.x;
     TrajState &S = st[b];
     if (!S.newton_active || !S.need_trial) return;
     double v[NPART];
     const int op[NPART] = {0, 0, 1, 2, 0, 0};
-    fin_reduce(part, nblk, b, v, op, 4);
+    // guess (MODE 0 only): k_guess has deflated the right-hand side; slot 1 holds sum (rhs - A x0)^2, slot 4 sum rhs^2
+    fin_reduce(part, nblk, b, v, op, (MODE == 0 && guess) ? 5 : 4);
     if (threadIdx.x != 0) return;
     const double nt = sqrt(v[0]);
     bool accept;
@@ -960,6 +1042,9 @@ __global__ void k_fin_residual(TrajState *st, const double *__restrict__ part, i
         S.Dmin = v[2];
         S.Dmax = v[3];
         S.lin_r0 = sqrt(v[1]);
+        S.x_primed = (MODE == 0 && guess) ? 1 : 0;
+        S.lin_rscale = (MODE == 0 && guess && v[4] > 0.0) ? fmin(1.0, sqrt(v[1] / v[4])) : 1.0;
+        if (MODE == 0) S.guess_ratio = (guess && v[4] > 0.0) ? sqrt(v[1] / v[4]) : 1.0;
         S.lin_reltol = newton_lin_tol(S.lin_r0, lin_tol, eta);
         cg_setup(S, 2.0 * sqrt(0.5 * kappa / dt), 1.0, S.lin_reltol);
         S.lin_active = 1;
@@ -1079,7 +1164,7 @@ __device__ __forceinline__ void cg_record(TrajState &S, const CgNext &n, int wr)
         S.lin_it = n.it;
         S.lin_total++;
     }
-    if (!n.active && n.rel > S.lin_maxrel) S.lin_maxrel = n.rel;
+    if (!n.active && n.rel * S.lin_rscale > S.lin_maxrel) S.lin_maxrel = n.rel * S.lin_rscale;
     if (!n.active) S.lin_maxabs = fmax(S.lin_maxabs, n.rel * S.lin_r0);
     if (n.it > S.step_lin_max) S.step_lin_max = n.it;
     if (S.step_solves >= 1 && S.step_solves <= 4 && n.it > S.step_lin[S.step_solves - 1]) S.step_lin[S.step_solves - 1] = n.it;
