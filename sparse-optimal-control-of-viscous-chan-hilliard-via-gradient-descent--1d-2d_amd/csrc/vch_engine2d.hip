@@ -1233,6 +1233,11 @@ static int backward_pass(vch2d_ctx *c, const double *phi_hist_dev, int M, const 
     VCHCHK(adjoint_solve_cg(c, 0.0, 3, false));
     int sweeps = -1, steps_since_look = 0;
     bool first_solve = true;
+    // starting guess of the solve for p_n (k_adj_guess; the forward ring dprev is free during the sweep): polynomial
+    // extrapolation in time over the levels n+2, n+4, .. n+2*order already solved.  order grows by one per look while the
+    // guess keeps paying, and the looks come every step until it has settled
+    const bool guess = c->guess_on && !safe && !getenv("VCH_ADJ_GUESS_OFF");
+    int order = 1, kept = 0, settled = 0;
     LAUNCH(k_adj_finish, c->grid, dim3(NTH), G, c->x, (const double *)nullptr, qa, rcur, 0.0, 0.0,
            r_out ? r_out + (long)M * G.plane : (double *)nullptr, p_out ? p_out + (long)M * G.plane : (double *)nullptr,
            q_out ? q_out + (long)M * G.plane : (double *)nullptr, hs);
@@ -1245,22 +1250,58 @@ static int backward_pass(vch2d_ctx *c, const double *phi_hist_dev, int M, const 
             if (rl) LAUNCH(k_copy_plane, c->grid, dim3(NTH), G, r_out + (long)(n + 1) * G.plane, hs, rl, hs);
             if (pl) LAUNCH(k_copy_plane, c->grid, dim3(NTH), G, p_out + (long)(n + 1) * G.plane, hs, pl, hs);
             if (ql) LAUNCH(k_copy_plane, c->grid, dim3(NTH), G, q_out + (long)(n + 1) * G.plane, hs, ql, hs);
+            kept = 0;                 // the ring would miss this level: start it again
             continue;
         }
         LAUNCHC(PC_ADJ_RHS, k_adj_rhs, c->grid, dim3(NTH), G, c->P, c->x, qa, phi_hist_dev + (long)n * G.plane,
                phi_hist_dev + (long)(n + 1) * G.plane, phiQ_dev ? phiQ_dev + (long)n * G.plane : (const double *)nullptr,
                phiQ_dev ? phiQ_dev + (long)(n + 1) * G.plane : (const double *)nullptr, hs, dtn, b1, rhs, Dn, c->part);
         LAUNCH(k_fin_lin_begin, dim3(c->B), dim3(64), c->st, c->part, c->nblk, 0, c->P.tau, c->P.kappa, dtn, c->lin_tol);
-        if (safe || steps_since_look >= ADJ_LOOK || sweeps < 0) {
+        if (safe || steps_since_look >= (guess && settled < 2 ? 1 : ADJ_LOOK) || sweeps < 0) {
             VCHCHK(sync_state(c, false));
             steps_since_look = 0;
             int longest = 0;
-            for (int b = 0; b < c->B; ++b) longest = std::max(longest, c->st_host[b].step_lin_max);
+            double worst = 0.0;
+            for (int b = 0; b < c->B; ++b) {
+                longest = std::max(longest, c->st_host[b].step_lin_max);
+                worst = std::max(worst, std::isfinite(c->st_host[b].guess_ratio) ? c->st_host[b].guess_ratio : 1e300);
+            }
             const int bound = cg_budget(c, false);
+            int margin = 1;
+            if (guess && !first_solve) {
+                // the state shows the solve of the previous level, started from a guess of the current order
+                const int before = order;
+                if (worst < 0.25) order = std::min(order + 1, GUESS_ORD / 2);
+                else if (worst > 0.7) order = std::max(order - 1, 1);
+                settled = order == before ? settled + 1 : 0;
+                if (order != before) margin = 2;
+                if (getenv("VCH_DEBUG_GUESS"))
+                    fprintf(stderr, "adjoint level %d: order %d -> %d ratio %.3e longest %d\n", n, before, order, worst, longest);
+                LAUNCH(k_reset_longest, dim3((c->B + 63) / 64), dim3(64), c->st, c->B);     // longest = since this look
+            }
             // the first solve of the sweep has nothing to go by: rigorous bound, with looks
-            sweeps = (safe || first_solve) ? bound : std::max(2, std::min(longest + 1, bound));
+            sweeps = (safe || first_solve) ? bound : std::max(2, std::min(longest + margin, bound));
         }
         ++steps_since_look;
+        if (guess) {
+            // c->x = p_{n+1} goes into the ring (slot kept mod GUESS_RING); level n+1+j was kept j saves ago.  The guess is
+            // the polynomial through the levels n+2k, k = 1..m, at t_n; nothing kept yet: p_{n+1} as it stands
+            const int m = std::min(order, (kept + 1) / 2);
+            GuessArgs ga;
+            for (int j = 0; j < GUESS_ORD; ++j) {
+                ga.c[j] = 0.0;
+                ga.d[j] = c->dprev[(kept - j) & (GUESS_RING - 1)];
+            }
+            if (m == 0) ga.c[0] = 1.0;
+            for (int j = 1; j <= m; ++j) {
+                double w = 1.0;
+                for (int k = 1; k <= m; ++k)
+                    if (k != j) w *= (t_hist[n] - t_hist[n + 2 * k]) / (t_hist[n + 2 * j] - t_hist[n + 2 * k]);
+                ga.c[2 * j - 1] = w;
+            }
+            LAUNCH(k_adj_guess, c->grid, dim3(NTH), G, c->x, ga, c->dprev[kept & (GUESS_RING - 1)]);
+            ++kept;
+        }
         VCHCHK(adjoint_solve_cg(c, dtn, sweeps, safe || first_solve));
         if (first_solve) { sweeps = -1; first_solve = false; }       // look again right after it
         const double den = c->P.gamma + 0.5 * dtn;

@@ -1020,6 +1020,7 @@ __global__ __launch_bounds__((FftThreads<C, LOGL>::T)) void k_adj_rows_fwd(Geom 
                 S.lin_reltol = a.tol;
                 S.aux[0] = r2;
                 S.lin_rel = rel;
+                S.guess_ratio = rel;             // ||rhs - A x0|| / ||rhs||: what the starting guess left (backward_pass)
                 if (!start) {
                     S.lin_active = 0;
                     if (rel > S.lin_maxrel) S.lin_maxrel = rel;

@@ -398,7 +398,7 @@ __global__ __launch_bounds__(NTH) void k_schur(Geom G, Phys P, const TrajState *
 // Any x0 is valid; non-finite entries of a stale d plane are read as 0.
 // ---------------------------------------------------------------------------------
 constexpr int GUESS_RING = 8;     // increments kept (a power of two)
-constexpr int GUESS_ORD = 6;      // at most this many enter the extrapolation
+constexpr int GUESS_ORD = 8;      // at most this many planes enter one guess (forward: <= 6 increments; adjoint: every second level)
 struct GuessArgs {
     const double *d[GUESS_ORD];   // first Newton increments of steps n-1 .. n-GUESS_ORD, [B][plane]
     double c[GUESS_ORD];          // their coefficients (0 = plane not used)
@@ -1402,6 +1402,35 @@ __global__ __launch_bounds__(NTH) void k_solve_w(Geom G, const double *__restric
             out[o] = ((gdt - 0.5) * w[o] + 0.5 * (u1 + u0)) / (gdt + 0.5);
         }
     }
+}
+
+// Adjoint sweep, starting guess of the solve for p_n (the solve starts from the content of x): x holds p_{n+1}; it is
+// saved into the ring slot `keep` and replaced by c_0 p_{n+1} + sum_{j>=1} c_j p_{n+1+j} over levels the ring holds.
+// Crank-Nicolson does not damp the highest modes (amplification -> -1), so p carries a component that alternates from
+// level to level and dominates the residual of a guess: p_{n+1} itself leaves ||rhs - A x0|| = 2 ||rhs||, p_{n+2} leaves
+// 1e-3 and the extrapolation over levels of the SAME parity, n+2, n+4, ..., 5e-6 and below (scripts/r2_extrap_adj.py).
+// backward_pass therefore sets c_0 = 0 and weights on j = 1, 3, 5, 7.
+__global__ __launch_bounds__(NTH) void k_adj_guess(Geom G, double *__restrict__ x, GuessArgs ga, double *__restrict__ keep) {
+    TILE_COORDS;
+    for (int k = 0; k < TY / 4; ++k) {
+        int r = r0 + ly0 + 4 * k, c = c0 + lx;
+        if (r < G.ns && c < G.nf) {
+            const long o = b * G.plane + (long)r * G.pitch + c;
+            const double p1 = x[o];
+            double v = ga.c[0] * p1;
+#pragma unroll
+            for (int j = 1; j < GUESS_ORD; ++j)
+                if (ga.c[j] != 0.0) v += ga.c[j] * ga.d[j][o];
+            keep[o] = p1;
+            x[o] = isfinite(v) ? v : p1;
+        }
+    }
+}
+
+// the longest solve since the host's last look (adjoint launch schedule)
+__global__ void k_reset_longest(TrajState *st, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) st[b].step_lin_max = 0;
 }
 
 // zero-fill / constant fill of valid nodes

@@ -406,21 +406,29 @@ def test_one_look_per_step_and_inexact_newton(V, O2):
     assert st3["linear_iters"] > st["linear_iters"], (st, st3)
     assert counts(st3) == counts(st), (st, st3)
     assert np.max(np.abs(ph3 - ph)) < 1e-10
+    # the starting guess of a step's first solve (extrapolated previous increments, deflated right-hand side): same
+    # Newton / Armijo counts as a march whose solves all start from zero, fewer sweeps, fields equal to solver tolerance
+    ph4, st4 = with_env("VCH_GUESS", "0")
+    assert counts(st4) == counts(st), (st, st4)
+    assert st["linear_iters"] < st4["linear_iters"], (st, st4)
+    assert np.max(np.abs(ph4 - ph)) < 1e-10
 
 
 def test_adjoint_sweep_schedule_independent(V, O2):
-    """The adjoint sweep's launch schedule (a look every 8 steps, sweeps per step from the longest solve so far) against
-    its fallback (VCH_ADJ_SAFE=1: a look and the rigorous sweep budget at every step): same p, q, r to solver round-off,
-    every solve converged (max_lin_relres at the 1e-15 tolerance), far fewer looks."""
+    """The adjoint sweep's launch schedule (a look every 8 steps once the order of the starting guess has settled, every
+    step while it is being raised; sweeps per step from the longest solve since the last look; each solve started from the
+    extrapolation over the levels n+2, n+4, ..) against its fallback (VCH_ADJ_SAFE=1: a look and the rigorous sweep budget
+    at every step, start from p_{n+1}): same p, q, r to solver round-off, every solve converged (max_lin_relres at the
+    1e-15 tolerance), far fewer looks, and fewer sweeps than the same schedule without the extrapolated start."""
     import os
-    N, M = 128, 24
+    N, M = 128, 64
     t, dts = V.time_grid(M * 1e-3, 1e-3)
     phi0 = np.stack([O2.init_phi_random(N, N, 1e-2, amp=0.1, seed=42 + i) for i in range(2)])
     phi_T = np.stack([_phi_T(N)] * 2)
     e = V.Engine2D(Nx=N, Ny=N, batch=2, max_steps=M)
     ph, _ = e.forward(phi0, dts)
     p, q, r, st = e.backward(ph, t, 5.0, 10.0, None, phi_T)
-    assert st["max_lin_relres"] < 2e-15 and st["host_syncs"] <= M // 8 + 6, st
+    assert st["max_lin_relres"] < 2e-15 and st["host_syncs"] <= M // 8 + 16, st
     os.environ["VCH_ADJ_SAFE"] = "1"
     try:
         p2, q2, r2, st2 = e.backward(ph, t, 5.0, 10.0, None, phi_T)
@@ -428,6 +436,13 @@ def test_adjoint_sweep_schedule_independent(V, O2):
         del os.environ["VCH_ADJ_SAFE"]
     assert st2["host_syncs"] >= M
     assert relerr(p, p2) < 1e-12 and relerr(q, q2) < 1e-10 and relerr(r, r2) < 1e-10, (st, st2)
+    os.environ["VCH_ADJ_GUESS_OFF"] = "1"
+    try:
+        p3, q3, r3, st3 = e.backward(ph, t, 5.0, 10.0, None, phi_T)
+    finally:
+        del os.environ["VCH_ADJ_GUESS_OFF"]
+    assert relerr(p, p3) < 1e-12 and relerr(r, r3) < 1e-10
+    assert st["linear_iters"] < 0.85 * st3["linear_iters"], (st, st3)
 
 
 def test_cost_collective_through_the_c_abi(V, O2):
