@@ -23,6 +23,58 @@ extern "C" int vch_device_count(void) {
 
 constexpr int J_RING = 64;        // iterations whose cost scalars stay readable on the device
 
+// How many previous increments the starting guess of a step's first Newton solve extrapolates over (forward_core).
+// The best order depends on the march: without a control the increments are smooth enough for order 6 (the deflated
+// right-hand side falls to 1e-9 of the full one), under a PGD control order 3-4 is the optimum, and in the spinodal
+// transient of the first steps no extrapolation pays.  So the order is found by trial: it climbs one step at a time while
+// each step more than halves the ratio ||rhs - A x0|| / ||rhs|| the guess leaves; afterwards every PROBE_EVERY-th step
+// tries the neighbouring order (alternately one up, one down) and the order moves if the neighbour is better (down on
+// ties: fewer planes to read).  A guess that leaves more than 0.7 of the right-hand side sends the order down at once.
+struct GuessPolicy {
+    static constexpr int PROBE_EVERY = 8;
+    int order, probe, since, next_dir;
+    bool climbing;
+    double r_base;
+    void reset() { order = 1; probe = 0; since = 0; next_dir = 1; climbing = true; r_base = 1e300; }
+    // order to use for the coming step; avail = increments kept so far, cap = largest order allowed
+    int choose(int avail, int cap) const { return std::max(0, std::min(std::min(order + probe, cap), avail)); }
+    // ratio left by the guess of the step just finished (worst trajectory), used = the order it was made with
+    void report(double r, int used, int cap) {
+        if (used < 1) return;
+        if (climbing) {
+            if (r > 0.7) {                                 // transient of the first steps: wait at order 1
+                order = std::max(1, used - 1);
+                r_base = 1e300;
+                if (used > 1) climbing = false;
+                return;
+            }
+            if (r_base < 1e299 && r > 0.5 * r_base) {      // the last step up did not pay: back, and hold
+                order = std::max(1, used - 1);
+                climbing = false;
+                return;
+            }
+            r_base = r;
+            order = used;
+            if (used >= cap) climbing = false;
+            else order = used + 1;
+            return;
+        }
+        if (probe == 0) {
+            r_base = r;
+            if (r > 0.7 && order > 1) { --order; since = 0; return; }
+            if (++since >= PROBE_EVERY) {
+                since = 0;
+                probe = next_dir;
+                next_dir = -next_dir;
+                if (order + probe < 1 || order + probe > cap) probe = 0;
+            }
+            return;
+        }
+        if (probe > 0 ? r < 0.5 * r_base : r <= r_base) order = used;
+        probe = 0;
+    }
+};
+
 struct vch2d_ctx {
     vch2d_params prm;
     int B, Mmax, device;
@@ -49,7 +101,8 @@ struct vch2d_ctx {
     bool guess_on;
     double guess_c[GUESS_ORD];            // coefficients of d_{n-1} .. d_{n-GUESS_ORD} (all 0: no guess this step)
     int guess_wr, guess_step;             // ring slot of this step's increment (-1: not kept); step index within the march
-    int guess_order, guess_max;           // increments the extrapolation uses (adapted from the ratio the last guess achieved)
+    int guess_used, guess_max;            // increments this step's guess extrapolates over; largest order allowed
+    GuessPolicy guess_pol;
     double *gpart2;                       // second half of gpart
     double *gpart3;                       // [2][B][gnblk + ns] partials of <z',z'>_Z of the stencil-free sweep
     double *gpart;                        // [B][gnblk] partials written by the GEMM epilogue
@@ -429,8 +482,9 @@ extern "C" vch2d_ctx *vch2d_create(const vch2d_params *p, int batch, int max_ste
     for (double &g : c->guess_c) g = 0.0;
     c->guess_wr = -1;
     c->guess_step = 0;
-    c->guess_order = 1;
-    c->guess_max = GUESS_ORD;
+    c->guess_used = 0;
+    c->guess_pol.reset();
+    c->guess_max = 6;          // beyond, the weights (sum |c_j| = 2^order - 1) amplify what the inexact solves left in the increments
     if (const char *e = getenv("VCH_GUESS_MAX")) c->guess_max = std::max(1, std::min(GUESS_ORD, atoi(e)));
     if (hipStreamSynchronize(c->stream) != hipSuccess) return fail("hipStreamSynchronize");
     return c;
@@ -748,7 +802,7 @@ static int newton_level(vch2d_ctx *c, double dt, const double *un, const double 
     if (getenv("VCH_DEBUG_GUESS")) {
         const TrajState &S = c->st_host[0];
         fprintf(stderr, "guess order %d c %.1f %.1f %.1f %.1f | traj 0: ratio %.3e solves %d sweeps %d %d %d normR %.3e active %d\n",
-                c->guess_order, c->guess_c[0], c->guess_c[1], c->guess_c[2], c->guess_c[3], S.guess_ratio, S.step_solves, S.step_lin[0],
+                c->guess_used, c->guess_c[0], c->guess_c[1], c->guess_c[2], c->guess_c[3], S.guess_ratio, S.step_solves, S.step_lin[0],
                 S.step_lin[1], S.step_lin[2], S.normR, S.newton_active);
     }
     int guard = 0;
@@ -1117,7 +1171,7 @@ static int forward_core(vch2d_ctx *c, const double *u_dev, int u_rows, const dou
     LAUNCH(k_mass, c->grid, dim3(NTH), c->G, c->st, c->slot_stride, c->phi_s, c->wts_mass, 0, c->part);
     LAUNCH(k_fin_mass, dim3(c->B), dim3(64), c->st, c->part, c->nblk, 1);
     if (hist_out) LAUNCH(k_copy_plane, c->grid, dim3(NTH), c->G, c->phi_s, c->G.plane, hist_out, hs);
-    c->guess_order = 1;
+    c->guess_pol.reset();
     for (int step = 0; step < M; ++step) {
         const double *un = nullptr, *unp1 = nullptr;
         if (u_dev && step < u_rows - 1) {        // F2:545-548
@@ -1132,7 +1186,8 @@ static int forward_core(vch2d_ctx *c, const double *u_dev, int u_rows, const dou
         c->guess_step = step;
         if (c->guess_on) {
             c->guess_wr = step & (GUESS_RING - 1);
-            const int m = std::min(std::min(step, c->guess_order), c->guess_max);
+            const int m = c->guess_pol.choose(step, c->guess_max);
+            c->guess_used = m;
             if (m >= 1) {
                 double mid[GUESS_ORD + 1];                    // midpoints of steps n, n-1, .. n-m relative to the start of step n
                 mid[0] = 0.5 * dt[step];
@@ -1156,9 +1211,7 @@ static int forward_core(vch2d_ctx *c, const double *u_dev, int u_rows, const dou
                hist_out ? hist_out + (long)(step + 1) * c->G.plane : (double *)nullptr, hs, (const double *)c->part);
         std::swap(c->w, c->wnew);
         if (c->guess_on && c->guess_c[0] != 0.0) {
-            // order for the next step from what this guess achieved (worst trajectory that solved): one more increment
-            // while the deflated right-hand side keeps shrinking, one less when the guess did not pay (the transient of
-            // the first steps, a kink of the control in time)
+            // what this guess achieved (worst trajectory that solved) decides the order of the next one (GuessPolicy)
             double worst = 0.0;
             bool any = false;
             for (int b = 0; b < c->B; ++b) {
@@ -1167,10 +1220,7 @@ static int forward_core(vch2d_ctx *c, const double *u_dev, int u_rows, const dou
                 any = true;
                 worst = std::max(worst, std::isfinite(S.guess_ratio) ? S.guess_ratio : 1e300);
             }
-            if (any) {
-                if (worst < 0.25) c->guess_order = std::min(c->guess_order + 1, GUESS_ORD);
-                else if (worst > 0.7) c->guess_order = std::max(c->guess_order - 1, 1);
-            }
+            if (any) c->guess_pol.report(worst, c->guess_used, c->guess_max);
         }
     }
     for (double &g : c->guess_c) g = 0.0;
