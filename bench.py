@@ -54,9 +54,12 @@ ALG_BYTES = {
     "residual": 88.0,        # trial form: phi, dphi, mu, dmu, c_phi, c_mu -> phi_t, mu_t, R_phi, rhs, D
     "adj_q": 64.0,           # first pass of an adjoint CG sweep (k_adj_rows_fwd): r, q, ph_old, y -> y, r', ph', E_rows(ph')
     "cg_update": 24.0, "adj_rhs": 72.0,
+    "guess": 80.0,           # k_guess at order 6: six increments, D, rhs -> rhs, x0
+    "adj_guess": 56.0,       # k_adj_guess at order 4: four levels, p -> ring, x0
 }
 PMC_NAMES = {"cg_rows_fwd": "k_cg_rows_fwd<0, 1024, 10>", "schur_p": "k_schur_p<0>", "dct_rows_fwd": "k_dct_rows<0, 1024, 10>", "dct_cols": "k_dct_cols<1024, 10>",
-             "dct_rows_inv": "k_dct_rows<3, 1024, 10>", "residual": "k_residual<1>", "adj_q": "k_adj_q"}
+             "dct_rows_inv": "k_dct_rows<3, 1024, 10>", "residual": "k_residual<1>", "adj_q": "k_adj_q", "guess": "k_guess",
+             "adj_guess": "k_adj_guess"}
 
 
 def parse():

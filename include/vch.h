@@ -243,8 +243,9 @@ int vch2d_free_energy(vch2d_ctx *ctx, const double *phi_hist, int rows, const do
  *   7 gradient+prox  8 DCT row pass (forward)  9 DCT column pass (forward, multiplier, inverse)
  *   10 DCT row pass (inverse, with the CG dot products)  11 first sweep of a solve (k_schur_p<1>)
  *   12 first pass of a CG sweep (k_cg_rows_fwd: CG vector updates + Delta p + forward row DCT)  13 the same, first sweep
- *   14 an empty kernel launched 256 times by _begin: the cost of an event pair itself */
-#define VCH_PROF_CLASSES 15
+ *   14 an empty kernel launched 256 times by _begin: the cost of an event pair itself
+ *   15 starting guess of a step's first Newton solve (k_guess)  16 starting guess of an adjoint solve (k_adj_guess) */
+#define VCH_PROF_CLASSES 17
 int vch2d_prof_begin(vch2d_ctx *ctx, int max_launches);
 int vch2d_prof_end(vch2d_ctx *ctx, double *ms_out, int64_t *count_out, int ncls);
 

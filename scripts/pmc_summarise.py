@@ -21,7 +21,9 @@ alg = {"k_cg_rows_fwd<0, 1024, 10>": (40, 32, "stream"), "k_cg_rows_fwd<1, 1024,
        "k_dct_cols<1024, 10>": (8, 8, "stream"), "k_adj_rows_fwd<0, 1024, 10>": (40, 32, "stream"),
        "k_residual<1>": (48, 40, "tile"), "k_residual<0>": (32, 32, "tile"), "k_prepare": (40, 32, "tile"),
        "k_dmu_ceiling_fin": (40, 16, "tile"), "k_adj_rhs": (48, 16, "tile"), "k_schur_p<0>": (40, 32, "tile"),
-       "k_copy_plane": (8, 8, "tile"), "k_grad_prox": (16, 8, "stream"), "k_cost": (24, 0, "stream")}
+       "k_copy_plane": (8, 8, "tile"), "k_grad_prox": (16, 8, "stream"), "k_cost": (24, 0, "stream"),
+       # starting guesses at their full order (six increments / four levels; the first steps of a march use fewer planes)
+       "k_guess": (64, 16, "tile"), "k_adj_guess": (40, 16, "tile")}
 res = {}
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     files = glob.glob(f"{out}/{ctr}/*/*counter_collection.csv")

@@ -15,7 +15,7 @@ for TAG in "$@"; do
   python - $(find $D -name "*kernel_stats.csv" | head -1) >> $O <<'PY'
 import csv,sys
 for r in csv.DictReader(open(sys.argv[1])):
-    if float(r["Percentage"])>1.5: print("%-44s %8s %8.2f us %6s %%"%(r["Name"].split("(")[0][:44],r["Calls"],float(r["AverageNs"])/1e3,r["Percentage"]))
+    if float(r["Percentage"])>0.8: print("%-44s %8s %8.2f us %6s %%"%(r["Name"].split("(")[0][:44],r["Calls"],float(r["AverageNs"])/1e3,r["Percentage"]))
 PY
   rm -rf $D
 done

@@ -186,7 +186,7 @@ struct vch2d_ctx {
 // Kernel classes for the in-situ timing of vch2d_prof_begin/_end.
 enum { PC_SCHUR_P = 0, PC_GEMM = 1, PC_RESIDUAL = 2, PC_ADJ_Q = 3, PC_CG_UPDATE = 4, PC_ADJ_RHS = 5, PC_COST = 6,
        PC_PROX = 7, PC_DCT_R0 = 8, PC_DCT_C = 9, PC_DCT_R3 = 10, PC_SCHUR_P1 = 11, PC_CG_ROWS = 12, PC_CG_ROWS1 = 13,
-       PC_NOOP = 14, PC_NCLS = 15 };
+       PC_NOOP = 14, PC_GUESS = 15, PC_ADJ_GUESS = 16, PC_NCLS = 17 };
 
 // an empty kernel: what an event pair measures around it is the cost of the pair itself (vch2d_prof_begin)
 __global__ void k_noop() {}
@@ -776,7 +776,7 @@ static int newton_level(vch2d_ctx *c, double dt, const double *un, const double 
             ga.d[j] = c->dprev[(c->guess_step - 1 - j) & (GUESS_RING - 1)];
             ga.c[j] = c->guess_c[j];
         }
-        LAUNCH(k_guess, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, ga, (const double *)c->D_s, dt, c->rhs_s, c->x0g,
+        LAUNCHC(PC_GUESS, k_guess, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, ga, (const double *)c->D_s, dt, c->rhs_s, c->x0g,
                c->part);
     }
     LAUNCH((k_fin_residual<0>), dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->hist_dev, c->P.kappa, dt, c->lin_tol, eta_,
@@ -1349,7 +1349,7 @@ static int backward_pass(vch2d_ctx *c, const double *phi_hist_dev, int M, const 
                     if (k != j) w *= (t_hist[n] - t_hist[n + 2 * k]) / (t_hist[n + 2 * j] - t_hist[n + 2 * k]);
                 ga.c[2 * j - 1] = w;
             }
-            LAUNCH(k_adj_guess, c->grid, dim3(NTH), G, c->x, ga, c->dprev[kept & (GUESS_RING - 1)]);
+            LAUNCHC(PC_ADJ_GUESS, k_adj_guess, c->grid, dim3(NTH), G, c->x, ga, c->dprev[kept & (GUESS_RING - 1)]);
             ++kept;
         }
         VCHCHK(adjoint_solve_cg(c, dtn, sweeps, safe || first_solve));
