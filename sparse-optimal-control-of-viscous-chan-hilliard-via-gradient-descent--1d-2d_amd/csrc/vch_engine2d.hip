@@ -103,6 +103,13 @@ struct vch2d_ctx {
     int guess_wr, guess_step;             // ring slot of this step's increment (-1: not kept); step index within the march
     int guess_used, guess_max;            // increments this step's guess extrapolates over; largest order allowed
     GuessPolicy guess_pol;
+    // the same for the step's SECOND Newton solve (its own ring; usable while every marching trajectory takes a second solve
+    // step after step: run2 = length of that run)
+    double *dprev2[GUESS_RING];
+    double guess_c2[GUESS_ORD];
+    int guess_used2, guess_run2;
+    bool guess2_on;
+    GuessPolicy guess_pol2;
     double *gpart2;                       // second half of gpart
     double *gpart3;                       // [2][B][gnblk + ns] partials of <z',z'>_Z of the stencil-free sweep
     double *gpart;                        // [B][gnblk] partials written by the GEMM epilogue
@@ -381,7 +388,7 @@ extern "C" vch2d_ctx *vch2d_create(const vch2d_params *p, int batch, int max_ste
     for (auto q : two)
         if (dalloc(q, 2 * bp, c->stream)) return fail("hipMalloc");
     double **one[] = {&c->w, &c->wnew, &c->mu0, &c->cphi, &c->cmu, &c->x, &c->r, &c->dmu, &c->t1, &c->t2,
-                      &c->cg_p[0], &c->cg_p[1], &c->cg_v, &c->cg_q, &c->cg_z2, &c->xf, &c->dprev[0], &c->dprev[1], &c->dprev[2], &c->dprev[3], &c->dprev[4], &c->dprev[5], &c->dprev[6], &c->dprev[7], &c->x0g, &c->tmp[0], &c->tmp[1], &c->tmp[2], &c->tmp[3], &c->tmp[4], &c->tmp[5], &c->phiT, &c->phi0};
+                      &c->cg_p[0], &c->cg_p[1], &c->cg_v, &c->cg_q, &c->cg_z2, &c->xf, &c->dprev[0], &c->dprev[1], &c->dprev[2], &c->dprev[3], &c->dprev[4], &c->dprev[5], &c->dprev[6], &c->dprev[7], &c->dprev2[0], &c->dprev2[1], &c->dprev2[2], &c->dprev2[3], &c->dprev2[4], &c->dprev2[5], &c->dprev2[6], &c->dprev2[7], &c->x0g, &c->tmp[0], &c->tmp[1], &c->tmp[2], &c->tmp[3], &c->tmp[4], &c->tmp[5], &c->phiT, &c->phi0};
     for (auto q : one)
         if (dalloc(q, bp, c->stream)) return fail("hipMalloc");
     if (dalloc(&c->wts_mass, G.plane, c->stream) || dalloc(&c->W_cost, G.plane, c->stream)) return fail("hipMalloc");
@@ -480,6 +487,10 @@ extern "C" vch2d_ctx *vch2d_create(const vch2d_params *p, int batch, int max_ste
     // starting guess of a step's first Newton solve (k_guess): stencil-free sweep only; VCH_GUESS=0 turns it off
     c->guess_on = c->use_fft && !c->half_f && !c->half_s && !(getenv("VCH_GUESS") && atoi(getenv("VCH_GUESS")) == 0);
     for (double &g : c->guess_c) g = 0.0;
+    for (double &g : c->guess_c2) g = 0.0;
+    c->guess_used2 = c->guess_run2 = 0;
+    c->guess_pol2.reset();
+    c->guess2_on = !(getenv("VCH_GUESS2") && atoi(getenv("VCH_GUESS2")) == 0);
     c->guess_wr = -1;
     c->guess_step = 0;
     c->guess_used = 0;
@@ -495,7 +506,7 @@ extern "C" void vch2d_destroy(vch2d_ctx *c) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     double *all[] = {c->phi_s, c->mu_s, c->Rphi_s, c->rhs_s, c->D_s, c->w, c->wnew, c->mu0, c->cphi, c->cmu, c->x,
-                     c->r, c->dmu, c->t1, c->t2, c->cg_p[0], c->cg_p[1], c->cg_v, c->cg_q, c->cg_z2, c->xf, c->dprev[0], c->dprev[1], c->dprev[2], c->dprev[3], c->dprev[4], c->dprev[5], c->dprev[6], c->dprev[7], c->x0g, c->gpart, c->gpart3, c->tmp[0], c->tmp[1], c->tmp[2], c->tmp[3], c->tmp[4], c->tmp[5],
+                     c->r, c->dmu, c->t1, c->t2, c->cg_p[0], c->cg_p[1], c->cg_v, c->cg_q, c->cg_z2, c->xf, c->dprev[0], c->dprev[1], c->dprev[2], c->dprev[3], c->dprev[4], c->dprev[5], c->dprev[6], c->dprev[7], c->dprev2[0], c->dprev2[1], c->dprev2[2], c->dprev2[3], c->dprev2[4], c->dprev2[5], c->dprev2[6], c->dprev2[7], c->x0g, c->gpart, c->gpart3, c->tmp[0], c->tmp[1], c->tmp[2], c->tmp[3], c->tmp[4], c->tmp[5],
                      c->phiT, c->phi0, c->wts_mass, c->W_cost, c->part, c->hist_dev, c->alpha_dev, c->J_dev, c->Q1f,
                      c->Q2f, c->Q1s, c->Q2s, c->mf, c->ms, c->phi_hist, c->u_hist, c->u_trial, c->phi_trial, c->phiQ,
                      c->r_hist, c->p_hist, c->q_hist, c->cost_part, c->cost_lvl, c->tfrac_dev};
@@ -730,7 +741,8 @@ static int dmu_ceiling(vch2d_ctx *c, int strict) {
                        c->cg_p[last & 1]};
         LAUNCH(k_dmu_ceiling_fin, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, (const double *)c->x, f, (const double *)c->phi_s,
                (const double *)c->D_s, (const double *)c->Rphi_s, c->dmu, c->xf, c->part,
-               c->guess_wr >= 0 ? c->dprev[c->guess_wr] : (double *)nullptr);
+               c->guess_wr >= 0 ? c->dprev[c->guess_wr] : (double *)nullptr,
+               (c->guess_wr >= 0 && c->guess2_on) ? c->dprev2[c->guess_wr] : (double *)nullptr);
         LAUNCH(k_fin_ceiling, dim3(c->B), dim3(64), c->st, c->part, c->nblk, strict, rd ^ 1);
     } else {
         LAUNCH(k_dmu_ceiling, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->x, c->phi_s, c->D_s, c->Rphi_s, c->dmu, c->xf,
@@ -745,8 +757,11 @@ static int dmu_ceiling(vch2d_ctx *c, int strict) {
     do {                                                                                                                    \
         LAUNCHC(PC_RESIDUAL, (k_residual<1>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s,     \
                 c->Rphi_s, c->rhs_s, c->D_s, c->mu0, c->xf, c->dmu, c->cphi, c->cmu, dt, c->part);                          \
+        if (guess2)                                                                                                         \
+            LAUNCHC(PC_GUESS, k_guess, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, ga2, (const double *)c->D_s,  \
+                    dt, c->rhs_s, c->x0g, c->part, 1);                                                                      \
         LAUNCH((k_fin_residual<1>), dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->hist_dev, c->P.kappa, dt, c->lin_tol, \
-               eta_, 0);                                                                                                   \
+               eta_, guess2 ? 1 : 0);                                                                                      \
     } while (0)
 
 // One implicit time level for the whole batch (F2:323-427).  On entry the old level is
@@ -777,7 +792,14 @@ static int newton_level(vch2d_ctx *c, double dt, const double *un, const double 
             ga.c[j] = c->guess_c[j];
         }
         LAUNCHC(PC_GUESS, k_guess, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, ga, (const double *)c->D_s, dt, c->rhs_s, c->x0g,
-               c->part);
+               c->part, 0);
+    }
+    // ... and of the second solve, inside every residual trial (RESIDUAL_TRIAL; k_guess picks the trajectories it applies to)
+    const bool guess2 = in_march && c->guess_on && c->guess2_on && c->guess_c2[0] != 0.0;
+    GuessArgs ga2;
+    for (int j = 0; j < GUESS_ORD; ++j) {
+        ga2.d[j] = c->dprev2[(c->guess_step - 1 - j) & (GUESS_RING - 1)];
+        ga2.c[j] = guess2 ? c->guess_c2[j] : 0.0;
     }
     LAUNCH((k_fin_residual<0>), dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->hist_dev, c->P.kappa, dt, c->lin_tol, eta_,
            guess ? 1 : 0);
@@ -801,8 +823,8 @@ static int newton_level(vch2d_ctx *c, double dt, const double *un, const double 
     };
     if (getenv("VCH_DEBUG_GUESS")) {
         const TrajState &S = c->st_host[0];
-        fprintf(stderr, "guess order %d c %.1f %.1f %.1f %.1f | traj 0: ratio %.3e solves %d sweeps %d %d %d normR %.3e active %d\n",
-                c->guess_used, c->guess_c[0], c->guess_c[1], c->guess_c[2], c->guess_c[3], S.guess_ratio, S.step_solves, S.step_lin[0],
+        fprintf(stderr, "guess order %d / %d (run %d) | traj 0: ratio %.3e / %.3e solves %d sweeps %d %d %d normR %.3e active %d\n",
+                c->guess_used, c->guess_used2, c->guess_run2, S.guess_ratio, S.guess_ratio2, S.step_solves, S.step_lin[0],
                 S.step_lin[1], S.step_lin[2], S.normR, S.newton_active);
     }
     int guard = 0;
@@ -1172,6 +1194,8 @@ static int forward_core(vch2d_ctx *c, const double *u_dev, int u_rows, const dou
     LAUNCH(k_fin_mass, dim3(c->B), dim3(64), c->st, c->part, c->nblk, 1);
     if (hist_out) LAUNCH(k_copy_plane, c->grid, dim3(NTH), c->G, c->phi_s, c->G.plane, hist_out, hs);
     c->guess_pol.reset();
+    c->guess_pol2.reset();
+    c->guess_run2 = 0;
     for (int step = 0; step < M; ++step) {
         const double *un = nullptr, *unp1 = nullptr;
         if (u_dev && step < u_rows - 1) {        // F2:545-548
@@ -1186,9 +1210,8 @@ static int forward_core(vch2d_ctx *c, const double *u_dev, int u_rows, const dou
         c->guess_step = step;
         if (c->guess_on) {
             c->guess_wr = step & (GUESS_RING - 1);
-            const int m = c->guess_pol.choose(step, c->guess_max);
-            c->guess_used = m;
-            if (m >= 1) {
+            auto weights = [&](int m, double *cf) {
+                if (m < 1) return;
                 double mid[GUESS_ORD + 1];                    // midpoints of steps n, n-1, .. n-m relative to the start of step n
                 mid[0] = 0.5 * dt[step];
                 double t0 = 0.0;
@@ -1200,9 +1223,14 @@ static int forward_core(vch2d_ctx *c, const double *u_dev, int u_rows, const dou
                     double w = 1.0;
                     for (int k = 1; k <= m; ++k)
                         if (k != j) w *= (mid[0] - mid[k]) / (mid[j] - mid[k]);
-                    c->guess_c[j - 1] = w * dt[step] / dt[step - j];
+                    cf[j - 1] = w * dt[step] / dt[step - j];
                 }
-            }
+            };
+            c->guess_used = c->guess_pol.choose(step, c->guess_max);
+            weights(c->guess_used, c->guess_c);
+            for (double &g : c->guess_c2) g = 0.0;
+            c->guess_used2 = c->guess2_on ? c->guess_pol2.choose(std::min(step, c->guess_run2), c->guess_max) : 0;
+            weights(c->guess_used2, c->guess_c2);
         }
         VCHCHK(newton_level(c, dt[step], un, unp1, hs, nullptr, true));
         // clip, mass fix, store (F2:562-585)
@@ -1222,8 +1250,28 @@ static int forward_core(vch2d_ctx *c, const double *u_dev, int u_rows, const dou
             }
             if (any) c->guess_pol.report(worst, c->guess_used, c->guess_max);
         }
+        if (c->guess_on && c->guess2_on) {
+            // second solves: the ring is usable while every marching trajectory takes one, step after step
+            bool all2 = true, anyb = false;
+            double worst2 = 0.0;
+            for (int b = 0; b < c->B; ++b) {
+                const TrajState &S = c->st_host[b];
+                if (S.frozen) continue;
+                anyb = true;
+                if (S.step_solves < 2) all2 = false;
+                worst2 = std::max(worst2, std::isfinite(S.guess_ratio2) ? S.guess_ratio2 : 1e300);
+            }
+            if (anyb && all2) {
+                c->guess_run2++;
+                if (c->guess_used2 >= 1) c->guess_pol2.report(worst2, c->guess_used2, c->guess_max);
+            } else {
+                c->guess_run2 = 0;
+                c->guess_pol2.reset();
+            }
+        }
     }
     for (double &g : c->guess_c) g = 0.0;
+    for (double &g : c->guess_c2) g = 0.0;
     c->guess_wr = -1;
     return 0;
 }

@@ -642,13 +642,15 @@ __global__ __launch_bounds__(NTH) void k_dmu_ceiling_fin(Geom G, Phys P, TrajSta
                                                          const double *__restrict__ phi_s, const double *__restrict__ D_s,
                                                          const double *__restrict__ Rphi_s, double *__restrict__ dmu,
                                                          double *__restrict__ x_out, double *__restrict__ part,
-                                                         double *__restrict__ x_keep) {
+                                                         double *__restrict__ x_keep, double *__restrict__ x_keep2) {
     TILE_COORDS;
     if (!st[b].newton_active || st[b].need_trial) return;
     __shared__ double sx[(TY + 2) * (TX + 2)];
     __shared__ double sred[NPART * 4];
     __shared__ double s3[3];
-    const bool keep = x_keep && st[b].iters == 1;       // the step's first Newton increment, for the next steps' k_guess
+    // the step's first / second Newton increment, for the next steps' k_guess
+    double *const keepp = st[b].iters == 1 ? x_keep : (st[b].iters == 2 ? x_keep2 : nullptr);
+    const bool keep = keepp != nullptr;
     constexpr int W = TX + 2;
     const long pb = b * G.plane;
     const int slot = st[b].slot;
@@ -676,7 +678,7 @@ __global__ __launch_bounds__(NTH) void k_dmu_ceiling_fin(Geom G, Phys P, TrajSta
             long o = pb + (long)r * G.pitch + c, os = slot * slot_stride + o;
             double d = sx[p];
             x_out[o] = d;
-            if (keep) x_keep[o] = d;
+            if (keep) keepp[o] = d;
             dmu[o] = 2.0 * ((-0.5 * P.kappa * lap_at<W>(sx, p, G.ax, G.ay) + D_s[os] * d) + Rphi_s[os]);
             double ph = phi_s[os];
             if (d > 0.0) acc[0] = fmin(acc[0], (1.0 - DELTA_SEP - ph) / d);

@@ -48,6 +48,7 @@ struct TrajState {
     int x_primed, guess_pad;
     double lin_rscale;
     double guess_ratio;        // ||rhs - A x0|| / ||rhs|| of this step's guess (uncapped), for the host's choice of the order
+    double guess_ratio2;       // the same for the guess of the step's SECOND Newton solve (0 = no such guess this step)
     // per time step, for the host's launch schedule: linear solves started and the longest of them
     int step_solves, step_lin_max;
     int step_lin[4];           // sweeps of the first four solves of the step
@@ -403,12 +404,19 @@ struct GuessArgs {
     const double *d[GUESS_ORD];   // first Newton increments of steps n-1 .. n-GUESS_ORD, [B][plane]
     double c[GUESS_ORD];          // their coefficients (0 = plane not used)
 };
+// which = 0: the step's first solve (right-hand side of the initial residual, iterate slot S.slot);  which = 1: its second
+// solve -- the kernel sits between a trial's k_residual<1> and k_fin_residual<1>, works on the slot the trial wrote
+// (1 - S.slot) and only for trajectories whose first solve is done (iters == 1); a trial that is then rejected
+// simply discards it (the next trial evaluates the right-hand side afresh and this kernel runs again).
 __global__ __launch_bounds__(NTH) void k_guess(Geom G, Phys P, const TrajState *__restrict__ st, long slot_stride,
                                                GuessArgs ga, const double *__restrict__ D_s, double dt,
-                                               double *__restrict__ rhs_s, double *__restrict__ x0, double *__restrict__ part) {
+                                               double *__restrict__ rhs_s, double *__restrict__ x0, double *__restrict__ part,
+                                               int which) {
     TILE_COORDS;
     const TrajState S = st[b];
     if (!S.newton_active || !S.need_trial) return;
+    if (which == 1 && S.iters != 1) return;
+    const int slot = which == 1 ? 1 - S.slot : S.slot;
     __shared__ double sx[(TY + 4) * (TX + 4)];
     __shared__ double stt[(TY + 2) * (TX + 2)];
     __shared__ double sred[4];
@@ -425,7 +433,7 @@ __global__ __launch_bounds__(NTH) void k_guess(Geom G, Phys P, const TrajState *
         sx[e] = isfinite(v) ? v : 0.0;
     }
     __syncthreads();
-    const double *Dp = D_s + S.slot * slot_stride + pb;
+    const double *Dp = D_s + slot * slot_stride + pb;
     for (int e = threadIdx.x; e < (TY + 2) * W1; e += NTH) {
         int ly = e / W1, lxx = e - ly * W1;
         int gr = refl(r0 - 1 + ly, G.ns), gc = refl(c0 - 1 + lxx, G.nf);
@@ -439,7 +447,7 @@ __global__ __launch_bounds__(NTH) void k_guess(Geom G, Phys P, const TrajState *
         int ly = ly0 + 4 * k, r = r0 + ly, c = c0 + lx;
         if (r < G.ns && c < G.nf) {
             int p1 = (ly + 1) * W1 + lx + 1, p2 = (ly + 2) * W2 + lx + 2;
-            long o = pb + (long)r * G.pitch + c, os = S.slot * slot_stride + o;
+            long o = pb + (long)r * G.pitch + c, os = slot * slot_stride + o;
             const double rh = rhs_s[os] - (sx[p2] * idt - lap_at<W1>(stt, p1, G.ax, G.ay));
             rhs_s[os] = rh;
             x0[o] = sx[p2];
@@ -961,6 +969,7 @@ __global__ void k_fin_newton_begin(TrajState *st) {
     S.x_primed = 0;
     S.lin_rscale = 1.0;
     S.guess_ratio = 1.0;
+    S.guess_ratio2 = 0.0;
 }
 
 // After k_residual: the Armijo test (F2:411-419) or the bookkeeping of the initial residual,
@@ -1007,8 +1016,10 @@ __global__ void k_fin_residual(TrajState *st, const double *__restrict__ part, i
     if (!S.newton_active || !S.need_trial) return;
     double v[NPART];
     const int op[NPART] = {0, 0, 1, 2, 0, 0};
-    // guess (MODE 0 only): k_guess has deflated the right-hand side; slot 1 holds sum (rhs - A x0)^2, slot 4 sum rhs^2
-    fin_reduce(part, nblk, b, v, op, (MODE == 0 && guess) ? 5 : 4);
+    // guess: k_guess has deflated the right-hand side (MODE 0: of the step's first solve; MODE 1: of its second solve, for
+    // a trajectory whose first solve is done); slot 1 holds sum (rhs - A x0)^2, slot 4 sum rhs^2
+    const bool primed = guess && (MODE == 0 || S.iters == 1);
+    fin_reduce(part, nblk, b, v, op, primed ? 5 : 4);
     if (threadIdx.x != 0) return;
     const double nt = sqrt(v[0]);
     bool accept;
@@ -1042,9 +1053,10 @@ __global__ void k_fin_residual(TrajState *st, const double *__restrict__ part, i
         S.Dmin = v[2];
         S.Dmax = v[3];
         S.lin_r0 = sqrt(v[1]);
-        S.x_primed = (MODE == 0 && guess) ? 1 : 0;
-        S.lin_rscale = (MODE == 0 && guess && v[4] > 0.0) ? fmin(1.0, sqrt(v[1] / v[4])) : 1.0;
-        if (MODE == 0) S.guess_ratio = (guess && v[4] > 0.0) ? sqrt(v[1] / v[4]) : 1.0;
+        S.x_primed = primed ? 1 : 0;
+        S.lin_rscale = (primed && v[4] > 0.0) ? fmin(1.0, sqrt(v[1] / v[4])) : 1.0;
+        if (MODE == 0) S.guess_ratio = (primed && v[4] > 0.0) ? sqrt(v[1] / v[4]) : 1.0;
+        else if (primed) S.guess_ratio2 = v[4] > 0.0 ? sqrt(v[1] / v[4]) : 1.0;
         S.lin_reltol = newton_lin_tol(S.lin_r0, lin_tol, eta);
         cg_setup(S, 2.0 * sqrt(0.5 * kappa / dt), 1.0, S.lin_reltol);
         S.lin_active = 1;

@@ -390,8 +390,11 @@ def test_pgd_batch_uneven_line_search(V, O2):
         e1.pgd_init(phi0[b], phi_T[b], t, opt, ramp=True, T=T)
         r1 = e1.pgd_iterate(4)
         assert np.array_equal(r4["attempts"][b], r1["attempts"][0])
-        assert np.allclose(r4["cost"][b], r1["cost"][0], rtol=1e-12)
-        assert relerr(u4[b], e1.pgd_get("u")) < 1e-10 and relerr(p4[b], e1.pgd_get("phi")) < 1e-10
+        # equal to the tolerance of the inexact Newton solves, not to round-off: the order of the solves' starting guess is
+        # chosen per batch (from its worst trajectory), so a trajectory's solves start from different guesses with
+        # different batch mates and end anywhere inside the same residual target
+        assert np.allclose(r4["cost"][b], r1["cost"][0], rtol=1e-10)
+        assert relerr(u4[b], e1.pgd_get("u")) < 2e-9 and relerr(p4[b], e1.pgd_get("phi")) < 2e-9
 
 
 # ---------------------------------------------------------------------------------------
