@@ -757,11 +757,11 @@ static int dmu_ceiling(vch2d_ctx *c, int strict) {
     do {                                                                                                                    \
         LAUNCHC(PC_RESIDUAL, (k_residual<1>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s,     \
                 c->Rphi_s, c->rhs_s, c->D_s, c->mu0, c->xf, c->dmu, c->cphi, c->cmu, dt, c->part);                          \
-        if (guess2)                                                                                                         \
+        if (guess2 && trial_guess_)                                                                                         \
             LAUNCHC(PC_GUESS, k_guess, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, ga2, (const double *)c->D_s,  \
                     dt, c->rhs_s, c->x0g, c->part, 1);                                                                      \
         LAUNCH((k_fin_residual<1>), dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->hist_dev, c->P.kappa, dt, c->lin_tol, \
-               eta_, guess2 ? 1 : 0);                                                                                      \
+               eta_, (guess2 && trial_guess_) ? 1 : 0);                                                                    \
     } while (0)
 
 // One implicit time level for the whole batch (F2:323-427).  On entry the old level is
@@ -780,7 +780,6 @@ static int newton_level(vch2d_ctx *c, double dt, const double *un, const double 
     const double eta_ = in_march ? c->lin_eta : 0.0;
     LAUNCH(k_prepare, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s, c->w, un, unp1, u_stride,
            wnew_in, dt, c->wnew, c->mu0, c->cphi, c->cmu);
-    LAUNCH(k_fin_newton_begin, dim3(c->B), dim3(64), c->st);
     LAUNCHC(PC_RESIDUAL, (k_residual<0>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s, c->Rphi_s, c->rhs_s,
            c->D_s, c->mu0, c->x, c->dmu, c->cphi, c->cmu, dt, c->part);
     // starting guess of the first solve (marches on the stencil-free path only; forward_core sets the coefficients)
@@ -807,6 +806,9 @@ static int newton_level(vch2d_ctx *c, double dt, const double *un, const double 
         for (int s = 0; s < c->spec_slots; ++s) {
             VCHCHK(schur_solve(c, dt, c->spec_cgb[s], false));
             VCHCHK(dmu_ceiling(c, 1));
+            // the trial of slot 0 is the one a second solve normally follows; a trajectory whose second solve comes later
+            // (a rejected trial, a first solve that did not fit its slot) starts it from zero
+            const bool trial_guess_ = s == 0;
             RESIDUAL_TRIAL();
         }
     }
@@ -833,6 +835,7 @@ static int newton_level(vch2d_ctx *c, double dt, const double *un, const double 
         VCHCHK(schur_solve(c, dt, cg_budget(c, true), true));
         VCHCHK(dmu_ceiling(c, 0));
         int tguard = 0;
+        const bool trial_guess_ = true;
         do {
             RESIDUAL_TRIAL();
             VCHCHK(sync_state(c, false));

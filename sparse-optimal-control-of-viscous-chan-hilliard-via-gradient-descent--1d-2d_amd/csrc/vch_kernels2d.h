@@ -231,6 +231,30 @@ __global__ __launch_bounds__(NTH) void k_init_mu(Geom G, Phys P, const double *_
     }
 }
 
+// Start of a Newton call: arm the initial residual evaluation (done by one thread of k_prepare: the fields it sets are
+// read by no other workgroup of that launch).
+__device__ __forceinline__ void newton_begin(TrajState &S) {
+    if (S.frozen) {
+        S.newton_active = S.need_trial = S.lin_active = 0;
+        return;
+    }
+    S.newton_active = 1;
+    S.need_trial = 1;
+    S.trial_no = 0;
+    S.force_accept = 1;     // the initial residual is always "accepted"
+    S.iters = 0;
+    S.stuck = 0;
+    S.alpha = 0.0;
+    S.lin_active = 0;
+    S.step_solves = 0;
+    S.step_lin_max = 0;
+    S.step_lin[0] = S.step_lin[1] = S.step_lin[2] = S.step_lin[3] = 0;
+    S.x_primed = 0;
+    S.lin_rscale = 1.0;
+    S.guess_ratio = 1.0;
+    S.guess_ratio2 = 0.0;
+}
+
 // ---------------------------------------------------------------------------------
 // Start of a time step (F2:545-551, F2:350-351).  From the old level (phi, mu, w) and the
 // control rows u_n, u_{n+1} (NULL = zeros) form
@@ -242,7 +266,7 @@ __global__ __launch_bounds__(NTH) void k_init_mu(Geom G, Phys P, const double *_
 // so that R_phi = (tau/dt) phi+ - kappa/2 L phi+ + c1 reglog(phi+) - mu+/2 + c_phi and
 // R_mu = phi+/dt - L mu+/2 + c_mu (F2:194-221 with the old-level terms pre-combined).
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(NTH) void k_prepare(Geom G, Phys P, const TrajState *__restrict__ st,
+__global__ __launch_bounds__(NTH) void k_prepare(Geom G, Phys P, TrajState *__restrict__ st,
                                                  long slot_stride, const double *__restrict__ phi_s,
                                                  const double *__restrict__ mu_s, const double *__restrict__ w,
                                                  const double *__restrict__ un, const double *__restrict__ unp1,
@@ -254,6 +278,7 @@ __global__ __launch_bounds__(NTH) void k_prepare(Geom G, Phys P, const TrajState
     __shared__ double sp[(TY + 2) * (TX + 2)];
     __shared__ double sm[(TY + 2) * (TX + 2)];
     constexpr int W = TX + 2;
+    if (blk == 0 && threadIdx.x == 0) newton_begin(st[b]);
     if (st[b].frozen) return;
     const int slot = st[b].slot;
     load_tile<1>(sp, phi_s + slot * slot_stride + b * G.plane, G, c0, r0);
@@ -945,31 +970,6 @@ constexpr int ARMIJO_TRIALS = 12;      // F2:398
 __global__ void k_set_frozen(TrajState *st, const int *__restrict__ flags, int B) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < B) st[b].frozen = flags[b];
-}
-
-// Start of a Newton call: arm the initial residual evaluation.
-__global__ void k_fin_newton_begin(TrajState *st) {
-    TrajState &S = st[blockIdx.x];
-    if (threadIdx.x != 0) return;
-    if (S.frozen) {
-        S.newton_active = S.need_trial = S.lin_active = 0;
-        return;
-    }
-    S.newton_active = 1;
-    S.need_trial = 1;
-    S.trial_no = 0;
-    S.force_accept = 1;     // the initial residual is always "accepted"
-    S.iters = 0;
-    S.stuck = 0;
-    S.alpha = 0.0;
-    S.lin_active = 0;
-    S.step_solves = 0;
-    S.step_lin_max = 0;
-    S.step_lin[0] = S.step_lin[1] = S.step_lin[2] = S.step_lin[3] = 0;
-    S.x_primed = 0;
-    S.lin_rscale = 1.0;
-    S.guess_ratio = 1.0;
-    S.guess_ratio2 = 0.0;
 }
 
 // After k_residual: the Armijo test (F2:411-419) or the bookkeeping of the initial residual,
