@@ -487,3 +487,40 @@ def test_bench_prints_exactly_one_json_line():
     out = json.loads(lines[0])
     assert out["config"]["collective"] == "cabi-rccl" and out["n_gpus"] == 1 and out["steps"] == 2
     assert out["value"] > 0 and out["roofline"] is not None and 0 < out["roofline"]["frac"] < 1
+
+
+def test_starting_guesses_ragged_steps_and_switching_control(V, O2):
+    """The extrapolated starting guesses of the Newton solves (first and second solve of a step) under what they assume
+    least: step sizes that change from step to step (the weights are the polynomial through the step midpoints) and a
+    control that switches sign abruptly half way (the order policy must fall back, not the solver).  Against the same
+    march with all solves started from zero (VCH_GUESS=0): equal Newton / Armijo counts, fields equal to the solves'
+    tolerance, and no more sweeps."""
+    import os
+    N, M = 64, 60
+    rng = np.random.default_rng(5)
+    dts = 1e-3 * (0.5 + rng.random(M))                      # ragged: 0.5 .. 1.5 ms
+    xs = np.linspace(0, 1, N + 1)
+    shape = np.sin(2 * np.pi * xs)[:, None] * np.cos(np.pi * xs)[None, :]
+    sign = np.where(np.arange(M + 1) < M // 2, 1.0, -1.0)   # switches at step M/2
+    u = np.stack([(a * sign)[:, None, None] * shape[None] for a in (2.0, -3.0)])
+    phi0 = np.stack([O2.init_phi_random(N, N, 1e-2, amp=0.1, seed=11 + i) for i in range(2)])
+
+    def march(env):
+        for k, v in env.items():
+            os.environ[k] = v
+        try:
+            e = V.Engine2D(Nx=N, Ny=N, batch=2, max_steps=M)
+            out = e.forward(phi0, dts, u=u)
+            e.close()
+            return out
+        finally:
+            for k in env:
+                del os.environ[k]
+    ph, st = march({})
+    ph0, st0 = march({"VCH_GUESS": "0"})
+    counts = lambda s: (s["newton_iters"], s["linear_solves"], s["armijo_trials"])
+    assert counts(st) == counts(st0), (st, st0)
+    assert st["linear_iters"] <= st0["linear_iters"], (st, st0)
+    assert np.max(np.abs(ph - ph0)) < 1e-9
+    ph1, st1 = march({"VCH_GUESS2": "0"})                   # only the first solve of a step guessed
+    assert counts(st1) == counts(st0) and np.max(np.abs(ph1 - ph0)) < 1e-9
