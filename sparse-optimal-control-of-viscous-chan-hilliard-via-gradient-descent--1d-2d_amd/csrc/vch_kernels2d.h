@@ -950,14 +950,23 @@ __global__ __launch_bounds__(NTH) void k_grad_prox(Geom G, int tiles_f, const do
 // =================================================================================
 __device__ __forceinline__ void fin_reduce(const double *part, int nblk, int b, double (&out)[NPART],
                                            const int (&op)[NPART], int n) {
-    for (int k = 0; k < n; ++k) {
-        double a = op[k] == 0 ? 0.0 : (op[k] == 1 ? 1e300 : -1e300);
-        for (int t = threadIdx.x; t < nblk; t += 64) {
-            double v = part[((long)b * nblk + t) * NPART + k];
-            a = op[k] == 0 ? a + v : (op[k] == 1 ? fmin(a, v) : fmax(a, v));
-        }
-        out[k] = op[k] == 0 ? wave_sum(a) : (op[k] == 1 ? wave_min(a) : wave_max(a));
+    // all n slots in one pass over the workgroups' partials (the loads of a pass are independent), then the n wavefront
+    // reductions side by side -- one slot after the other made this a chain of n x (loads + 6 shuffle steps)
+    double a[NPART];
+#pragma unroll
+    for (int k = 0; k < NPART; ++k) a[k] = op[k] == 0 ? 0.0 : (op[k] == 1 ? 1e300 : -1e300);
+    for (int t = threadIdx.x; t < nblk; t += 64) {
+        const double *p = part + ((long)b * nblk + t) * NPART;
+#pragma unroll
+        for (int k = 0; k < NPART; ++k)
+            if (k < n) {
+                const double v = p[k];
+                a[k] = op[k] == 0 ? a[k] + v : (op[k] == 1 ? fmin(a[k], v) : fmax(a[k], v));
+            }
     }
+#pragma unroll
+    for (int k = 0; k < NPART; ++k)
+        if (k < n) out[k] = op[k] == 0 ? wave_sum(a[k]) : (op[k] == 1 ? wave_min(a[k]) : wave_max(a[k]));
 }
 
 constexpr int HIST_CAP = 512;          // >= max_iter + 1 residual norms (F2:353)
@@ -1009,10 +1018,16 @@ __device__ __forceinline__ double newton_lin_tol(double r0, double lin_tol, doub
 }
 
 template <int MODE>
+__device__ __forceinline__ void fin_residual_update(TrajState &S, const double (&v)[NPART], bool primed, double *__restrict__ hist,
+                                                    double kappa, double dt, double lin_tol, double eta);
+
+template <int MODE>
 __global__ void k_fin_residual(TrajState *st, const double *__restrict__ part, int nblk,
                                double *__restrict__ hist, double kappa, double dt, double lin_tol, double eta, int guess) {
     const int b = blockIdx.x;
-    TrajState &S = st[b];
+    // the record is worked on in registers and written back once: through a reference every field access is a global
+    // memory round trip and the state machine below a chain of them (one workgroup, nothing to hide them behind)
+    TrajState S = st[b];
     if (!S.newton_active || !S.need_trial) return;
     double v[NPART];
     const int op[NPART] = {0, 0, 1, 2, 0, 0};
@@ -1021,6 +1036,13 @@ __global__ void k_fin_residual(TrajState *st, const double *__restrict__ part, i
     const bool primed = guess && (MODE == 0 || S.iters == 1);
     fin_reduce(part, nblk, b, v, op, primed ? 5 : 4);
     if (threadIdx.x != 0) return;
+    fin_residual_update<MODE>(S, v, primed, hist + (long)b * HIST_CAP, kappa, dt, lin_tol, eta);
+    st[b] = S;
+}
+
+template <int MODE>
+__device__ __forceinline__ void fin_residual_update(TrajState &S, const double (&v)[NPART], bool primed, double *__restrict__ hist,
+                                                    double kappa, double dt, double lin_tol, double eta) {
     const double nt = sqrt(v[0]);
     bool accept;
     if (MODE == 0) {
@@ -1039,7 +1061,7 @@ __global__ void k_fin_residual(TrajState *st, const double *__restrict__ part, i
         S.normR = nt;
         S.need_trial = 0;
         S.force_accept = 0;
-        if (S.iters < HIST_CAP) hist[(long)b * HIST_CAP + S.iters] = nt;
+        if (S.iters < HIST_CAP) hist[S.iters] = nt;
         S.iters++;
         S.newton_total++;
         // F2:364: converged; F2:356: the loop body runs at most max_iter times
@@ -1079,7 +1101,7 @@ __global__ void k_fin_residual(TrajState *st, const double *__restrict__ part, i
                 S.stuck = 1;
                 S.need_trial = 0;
                 while (S.iters < NEWTON_MAXIT) {
-                    if (S.iters < HIST_CAP) hist[(long)b * HIST_CAP + S.iters] = S.normR;
+                    if (S.iters < HIST_CAP) hist[S.iters] = S.normR;
                     S.iters++;
                 }
                 S.newton_active = 0;
@@ -1265,12 +1287,14 @@ __global__ void k_fin_cg_beta(TrajState *st, const double *__restrict__ part, in
 // fin_copy of the per-sweep state, from which lin_active is taken over here.
 __global__ void k_fin_ceiling(TrajState *st, const double *__restrict__ part, int nblk, int strict, int fin_copy) {
     const int b = blockIdx.x;
-    TrajState &S = st[b];
+    TrajState S = st[b];                    // in registers, written back once (see k_fin_residual)
     if (!S.newton_active || S.need_trial) return;
     if (fin_copy >= 0 && S.lin_active) {
-        __syncthreads();                                       // every thread has read lin_active
-        if (threadIdx.x == 0) S.lin_active = S.ci_active[fin_copy];
-        __syncthreads();
+        S.lin_active = fin_copy == 0 ? S.ci_active[0] : S.ci_active[1];
+        if (strict && S.lin_active) {       // unfinished: only the flag goes back
+            if (threadIdx.x == 0) st[b].lin_active = S.lin_active;
+            return;
+        }
     }
     if (strict && S.lin_active) return;
     double v[NPART];
@@ -1290,6 +1314,7 @@ __global__ void k_fin_ceiling(TrajState *st, const double *__restrict__ part, in
     S.force_accept = 0;
     S.best_norm = 1e300;
     S.best_alpha = S.alpha;
+    st[b] = S;
 }
 
 __global__ void k_fin_mass(TrajState *st, const double *__restrict__ part, int nblk, int init) {
