@@ -94,9 +94,10 @@ struct vch2d_ctx {
     double *cg_z2;                        // second residual buffer of the forward CG (z ping-pongs r <-> cg_z2)
     double *xf;                           // finished dphi of a Newton solve (written by the back-substitution kernel)
     int cg_last;                          // index of the last sweep schur_solve enqueued (-1: none), for dmu_ceiling()
-    // starting guess of a step's first Newton solve (k_guess): first increments of the two previous steps (ring, written by
-    // k_dmu_ceiling_fin), the guess itself, its coefficients for the step being enqueued (0, 0 = no guess) and the ring
-    // slot this step's increment goes to
+    // starting guess of a step's first Newton solve (k_guess): the first increments of the last GUESS_RING steps (ring,
+    // written by k_dmu_ceiling_fin; the adjoint sweep keeps its levels there instead), the guess itself (also that of the
+    // second solve), its coefficients for the step being enqueued (all 0 = no guess) and the ring slot this step's
+    // increment goes to
     double *dprev[GUESS_RING], *x0g;
     bool guess_on;
     double guess_c[GUESS_ORD];            // coefficients of d_{n-1} .. d_{n-GUESS_ORD} (all 0: no guess this step)

@@ -43,8 +43,9 @@ struct TrajState {
     // the Schur residual it leaves -- which is the nonlinear residual of the next iterate up to second-order terms --
     // is a small fraction of the Newton tolerance; lin_maxabs = worst (final relative residual x ||rhs||_2) of a solve
     double lin_reltol, lin_maxabs;
-    // starting guess of the step's first Newton solve (k_guess): the sweeps start from x = x0 instead of 0 and solve for the
-    // deflated right-hand side rhs - A x0; lin_rscale = ||rhs - A x0|| / ||rhs|| keeps lin_maxrel relative to ||rhs||
+    // starting guess of the step's first / second Newton solve (k_guess): the sweeps of THIS solve start from x = x0 instead
+    // of 0 and solve for the deflated right-hand side rhs - A x0; lin_rscale = ||rhs - A x0|| / ||rhs|| keeps lin_maxrel
+    // relative to ||rhs||
     int x_primed, guess_pad;
     double lin_rscale;
     double guess_ratio;        // ||rhs - A x0|| / ||rhs|| of this step's guess (uncapped), for the host's choice of the order
