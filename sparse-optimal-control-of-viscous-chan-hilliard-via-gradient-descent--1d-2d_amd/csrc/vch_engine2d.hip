@@ -408,12 +408,24 @@ extern "C" vch2d_ctx *vch2d_create(const vch2d_params *p, int batch, int max_ste
     hipMemsetAsync(c->st, 0, sizeof(TrajState) * batch, c->stream);
     if (hipMalloc((void **)&c->frozen_dev, sizeof(int) * batch) != hipSuccess) return fail("hipMalloc");
     if (hipHostMalloc((void **)&c->st_host, sizeof(TrajState) * batch) != hipSuccess) return fail("hipHostMalloc");
-    if (hipHostMalloc((void **)&c->st_pub, sizeof(TrajState) * batch, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
-        hipHostMalloc((void **)&c->seq_pub, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess)
-        return fail("hipHostMalloc (mapped)");
-    *c->seq_pub = 0;
+    // looks through mapped host memory (sync_state); where the platform refuses mapped coherent memory the looks fall back
+    // to a copy command and a stream synchronisation
+    c->st_pub = nullptr;
+    c->seq_pub = nullptr;
     c->seq_next = 0;
     c->look_spin = !(getenv("VCH_LOOK_SPIN") && atoi(getenv("VCH_LOOK_SPIN")) == 0);
+    if (c->look_spin) {
+        if (hipHostMalloc((void **)&c->st_pub, sizeof(TrajState) * batch, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+            hipHostMalloc((void **)&c->seq_pub, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+            (void)hipGetLastError();
+            if (c->st_pub) hipHostFree(c->st_pub);
+            c->st_pub = nullptr;
+            c->seq_pub = nullptr;
+            c->look_spin = false;
+        } else {
+            *c->seq_pub = 0;
+        }
+    }
     if (hipHostMalloc((void **)&c->hist_host, sizeof(double) * batch * HIST_CAP) != hipSuccess) return fail("hipHostMalloc");
     c->phi_hist = c->u_hist = c->u_trial = c->phi_trial = c->phiQ = c->r_hist = c->p_hist = c->q_hist = nullptr;
     c->cost_part = c->cost_lvl = nullptr;
@@ -520,8 +532,8 @@ extern "C" void vch2d_destroy(vch2d_ctx *c) {
     if (c->tw_f) hipFree(c->tw_f);
     if (c->tw_s) hipFree(c->tw_s);
     hipHostFree(c->st_host);
-    hipHostFree(c->st_pub);
-    hipHostFree(c->seq_pub);
+    if (c->st_pub) hipHostFree(c->st_pub);
+    if (c->seq_pub) hipHostFree(c->seq_pub);
     hipHostFree(c->hist_host);
     hipHostFree(c->J_ring_host);
     hipFree(c->J_ring_dev);
