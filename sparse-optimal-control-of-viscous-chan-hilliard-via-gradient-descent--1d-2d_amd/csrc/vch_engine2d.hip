@@ -1226,27 +1226,33 @@ static int forward_core(vch2d_ctx *c, const double *u_dev, int u_rows, const dou
         c->guess_step = step;
         if (c->guess_on) {
             c->guess_wr = step & (GUESS_RING - 1);
-            auto weights = [&](int m, double *cf) {
-                if (m < 1) return;
-                double mid[GUESS_ORD + 1];                    // midpoints of steps n, n-1, .. n-m relative to the start of step n
-                mid[0] = 0.5 * dt[step];
-                double t0 = 0.0;
-                for (int j = 1; j <= m; ++j) {
-                    t0 -= dt[step - j];
-                    mid[j] = t0 + 0.5 * dt[step - j];
+            // returns the order actually used: on ragged time grids the weights of a high order can grow large, and a guess
+            // of large magnitude costs accuracy when the solve cancels it again (x = x0 + y); the weights of order 6 on a
+            // uniform grid sum to 63 in magnitude, anything above is answered with a lower order
+            auto weights = [&](int m, double *cf) -> int {
+                for (; m >= 1; --m) {
+                    double mid[GUESS_ORD + 1];                // midpoints of steps n, n-1, .. n-m relative to the start of step n
+                    mid[0] = 0.5 * dt[step];
+                    double t0 = 0.0, mag = 0.0;
+                    for (int j = 1; j <= m; ++j) {
+                        t0 -= dt[step - j];
+                        mid[j] = t0 + 0.5 * dt[step - j];
+                    }
+                    for (int j = 0; j < GUESS_ORD; ++j) cf[j] = 0.0;
+                    for (int j = 1; j <= m; ++j) {   // Lagrange weight of node j at mid[0]
+                        double w = 1.0;
+                        for (int k = 1; k <= m; ++k)
+                            if (k != j) w *= (mid[0] - mid[k]) / (mid[j] - mid[k]);
+                        cf[j - 1] = w * dt[step] / dt[step - j];
+                        mag += std::fabs(cf[j - 1]);
+                    }
+                    if (std::isfinite(mag) && mag <= 64.0) return m;
                 }
-                for (int j = 1; j <= m; ++j) {       // Lagrange weight of node j at mid[0]
-                    double w = 1.0;
-                    for (int k = 1; k <= m; ++k)
-                        if (k != j) w *= (mid[0] - mid[k]) / (mid[j] - mid[k]);
-                    cf[j - 1] = w * dt[step] / dt[step - j];
-                }
+                for (int j = 0; j < GUESS_ORD; ++j) cf[j] = 0.0;
+                return 0;
             };
-            c->guess_used = c->guess_pol.choose(step, c->guess_max);
-            weights(c->guess_used, c->guess_c);
-            for (double &g : c->guess_c2) g = 0.0;
-            c->guess_used2 = c->guess2_on ? c->guess_pol2.choose(std::min(step, c->guess_run2), c->guess_max) : 0;
-            weights(c->guess_used2, c->guess_c2);
+            c->guess_used = weights(c->guess_pol.choose(step, c->guess_max), c->guess_c);
+            c->guess_used2 = weights(c->guess2_on ? c->guess_pol2.choose(std::min(step, c->guess_run2), c->guess_max) : 0, c->guess_c2);
         }
         VCHCHK(newton_level(c, dt[step], un, unp1, hs, nullptr, true));
         // clip, mass fix, store (F2:562-585)
@@ -1406,12 +1412,22 @@ static int backward_pass(vch2d_ctx *c, const double *phi_hist_dev, int M, const 
                 ga.c[j] = 0.0;
                 ga.d[j] = c->dprev[(kept - j) & (GUESS_RING - 1)];
             }
-            if (m == 0) ga.c[0] = 1.0;
-            for (int j = 1; j <= m; ++j) {
-                double w = 1.0;
-                for (int k = 1; k <= m; ++k)
-                    if (k != j) w *= (t_hist[n] - t_hist[n + 2 * k]) / (t_hist[n + 2 * j] - t_hist[n + 2 * k]);
-                ga.c[2 * j - 1] = w;
+            int mu = m;
+            for (; mu >= 1; --mu) {                      // weights of large magnitude (ragged time grids): a lower order
+                double mag = 0.0;
+                for (int j = 0; j < GUESS_ORD; ++j) ga.c[j] = 0.0;
+                for (int j = 1; j <= mu; ++j) {
+                    double w = 1.0;
+                    for (int k = 1; k <= mu; ++k)
+                        if (k != j) w *= (t_hist[n] - t_hist[n + 2 * k]) / (t_hist[n + 2 * j] - t_hist[n + 2 * k]);
+                    ga.c[2 * j - 1] = w;
+                    mag += std::fabs(w);
+                }
+                if (std::isfinite(mag) && mag <= 64.0) break;
+            }
+            if (mu == 0) {
+                for (int j = 0; j < GUESS_ORD; ++j) ga.c[j] = 0.0;
+                ga.c[0] = 1.0;                           // p_{n+1} as it stands
             }
             LAUNCHC(PC_ADJ_GUESS, k_adj_guess, c->grid, dim3(NTH), G, c->x, ga, c->dprev[kept & (GUESS_RING - 1)]);
             ++kept;
