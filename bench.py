@@ -5,7 +5,8 @@ steps, batch of 64 random initial conditions sharded over 8 GPUs = 8 trajectorie
 (weak scaling: the per-GPU batch is fixed as N grows).
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: either under a launcher -- python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+     -- or bare, in which case this process starts the N ranks itself as child processes, spawn_ranks)
 
 A "step" is one proximal-gradient iteration for every trajectory of the batch = one pass of
 the reference's loop body (GD2_configured.py:295-382): adjoint sweep (1000 linear solves) +
@@ -170,9 +171,56 @@ class DryEngine:
 RESULT_OUT = None      # the process's real stdout, kept for the one JSON line (see main)
 
 
+def spawn_ranks(a):
+    """`python bench.py --gpus N` started WITHOUT a launcher (no RANK / WORLD_SIZE in the environment): start the N ranks
+    as child processes of this one -- which has not imported torch or the engine and has made no HIP call, and which is
+    never replaced by another program -- with the env:// rendezvous variables torch.distributed.run would set, pass rank 0's
+    single JSON line through and exit with the worst child status.  A rank that fails ends the others."""
+    import socket
+    import subprocess
+    n = a.gpus
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=(subprocess.PIPE if r == 0 else subprocess.DEVNULL), text=True))
+    line = None
+    worst = 0
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            pending.discard(r)
+            if rc != 0:
+                worst = worst or rc
+                for q in pending:                 # the failed rank's peers would wait in the next collective
+                    procs[q].terminate()
+        if pending:
+            time.sleep(0.05)
+    out0 = procs[0].stdout.read() if procs[0].stdout else ""
+    for ln in out0.splitlines():
+        if ln.startswith("{"):
+            line = ln
+    if worst == 0 and line is None:
+        print("[bench] rank 0 printed no result line", file=sys.stderr)
+        worst = 1
+    if line is not None and worst == 0:
+        print(line, flush=True)
+    sys.exit(worst if worst >= 0 else 1)
+
+
 def main():
     global RESULT_OUT
     a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(a)
     # stdout carries exactly one line, the JSON result: libraries that print banners on file descriptor 1 (RCCL
     # prints its version block there when a communicator is created) are sent to stderr instead
     sys.stdout.flush()

@@ -98,6 +98,39 @@ def test_bench_failing_rank_does_not_hang_its_peer():
     assert "injected failure" in (r.stdout + r.stderr)
 
 
+def _run_bench_bare(args, timeout=300):
+    """`python bench.py --gpus N ...` with NO launcher and no rendezvous variables in the environment: bench.py starts
+    its own ranks (spawn_ranks)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, cwd=root, env=env, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+def test_bench_bare_command_spawns_its_own_ranks():
+    """The driver's command form, `python bench.py --gpus 2 ...` without torchrun: the parent starts two child ranks
+    (gloo here), relays rank 0's single JSON line and exits 0."""
+    import json
+    r = _run_bench_bare(["--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run", "--contexts", "2", "--batch-per-gpu", "4"])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak"
+    assert out["config"]["collective"] == "gloo" and out["config"]["parallelism"] == "batch-shard x2"
+    assert np.allclose(out["cost_sum_per_step"], [8.0 / k for k in (2, 3, 4)])
+
+
+def test_bench_bare_command_failing_rank_exits_nonzero():
+    r = _run_bench_bare(["--gpus", "2", "--steps", "2", "--warmup", "0", "--dry-run", "--contexts", "1", "--batch-per-gpu", "2",
+                         "--dry-run-fail-rank", "1"], timeout=240)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
 def test_source_hash_drives_rebuild(tmp_path):
     """Build staleness is decided by a content hash of the sources recorded beside the library, not by mtimes."""
     import importlib
