@@ -94,6 +94,11 @@ struct vch2d_ctx {
     double *cg_z2;                        // second residual buffer of the forward CG (z ping-pongs r <-> cg_z2)
     double *xf;                           // finished dphi of a Newton solve (written by the back-substitution kernel)
     int cg_last;                          // index of the last sweep schur_solve enqueued (-1: none), for dmu_ceiling()
+    // reduction-free (Chebyshev) form of the forward solves of a march (cheb_solve): allowed at all (VCH_CHEB=0 turns it
+    // off), chosen for the step being enqueued, sweeps enqueued by the last cheb_solve (-1: the last solve was a CG solve),
+    // sweeps per Newton slot of the schedule, and the margin added to what the previous step's plans asked for
+    bool cheb_on, cheb_step;
+    int cheb_enq, spec_chn[4], cheb_margin, cheb_max;
     // starting guess of a step's first Newton solve (k_guess): the first increments of the last GUESS_RING steps (ring,
     // written by k_dmu_ceiling_fin; the adjoint sweep keeps its levels there instead), the guess itself (also that of the
     // second solve), its coefficients for the step being enqueued (all 0 = no guess) and the ring slot this step's
@@ -194,7 +199,7 @@ struct vch2d_ctx {
 // Kernel classes for the in-situ timing of vch2d_prof_begin/_end.
 enum { PC_SCHUR_P = 0, PC_GEMM = 1, PC_RESIDUAL = 2, PC_ADJ_Q = 3, PC_CG_UPDATE = 4, PC_ADJ_RHS = 5, PC_COST = 6,
        PC_PROX = 7, PC_DCT_R0 = 8, PC_DCT_C = 9, PC_DCT_R3 = 10, PC_SCHUR_P1 = 11, PC_CG_ROWS = 12, PC_CG_ROWS1 = 13,
-       PC_NOOP = 14, PC_GUESS = 15, PC_ADJ_GUESS = 16, PC_NCLS = 17 };
+       PC_NOOP = 14, PC_GUESS = 15, PC_ADJ_GUESS = 16, PC_CHEB_ROWS = 17, PC_CHEB_ROWS0 = 18, PC_NCLS = 19 };
 
 // an empty kernel: what an event pair measures around it is the cost of the pair itself (vch2d_prof_begin)
 __global__ void k_noop() {}
@@ -376,6 +381,14 @@ extern "C" vch2d_ctx *vch2d_create(const vch2d_params *p, int batch, int max_ste
     c->spec = getenv("VCH_NO_SPEC") == nullptr;
     c->spec_slots = 2;
     for (int &n : c->spec_cgb) n = 12;
+    c->cheb_on = !(getenv("VCH_CHEB") && atoi(getenv("VCH_CHEB")) == 0);
+    c->cheb_step = false;
+    c->cheb_enq = -1;
+    for (int &n : c->spec_chn) n = 2;
+    c->cheb_margin = 1;
+    if (const char *e = getenv("VCH_CHEB_MARGIN")) c->cheb_margin = std::max(0, atoi(e));
+    c->cheb_max = 6;           // plans longer than this (a wide spectrum: CG's adaptivity pays) keep the CG form
+    if (const char *e = getenv("VCH_CHEB_MAX")) c->cheb_max = std::max(0, atoi(e));
     c->n_launch = c->n_sync = 0;
     auto fail = [&](const char *what) {
         vch_fail(VCH_ERR_HIP, "vch2d_create: %s failed: %s", what, hipGetErrorString(hipGetLastError()));
@@ -681,6 +694,7 @@ constexpr int CG_CHUNK = 24;      // iterations enqueued between two looks at th
 // solving -- converged, frozen, or waiting for an Armijo trial -- keep their x.
 static int schur_solve(vch2d_ctx *c, double dt, int budget, bool look) {
     c->cg_last = -1;
+    c->cheb_enq = -1;
     if (budget <= 0) return 0;
     const double c0 = 1.0 / dt, c2 = 0.5 * c->P.kappa;
     double *zb[2] = {c->r, c->cg_z2};               // z_k lives in zb[k & 1]
@@ -745,24 +759,84 @@ static int schur_solve(vch2d_ctx *c, double dt, int budget, bool look) {
     return 0;
 }
 
+// The same solve in the reduction-free form (vch_fft.h, k_cheb_rows): `n_enq` sweeps are enqueued, every trajectory runs
+// the number its own plan asks for (TrajState::cheb_n, set with the solve's tolerance by k_fin_residual) and stores its
+// finished increment x0 + y in c->x; one whose plan is longer than n_enq is left unfinished (k_fin_ceiling).
+static int cheb_solve(vch2d_ctx *c, double dt, int n_enq) {
+    c->cg_last = -1;
+    c->cheb_enq = n_enq;
+    const Geom &G = c->G;
+    const int ns = G.ns, nf = G.nf;
+    const double c0 = 1.0 / dt, c2 = 0.5 * c->P.kappa;
+    const double scale = 1.0 / (4.0 * (double)c->fax.N * (double)c->sax.N);
+    {   // E_rows(rhs), then E_cols, 1 / P(m), E_cols (the transform pair's scale is applied by k_cheb_rows)
+        SpecArgs sp{c0, 0.0, 1.0, c2, c->ms, c->mf, nullptr, c->D_s, c->slot_stride, c->gpart, c->gpart2, 0};
+        const int gate = 1;
+        DCT_ROWS_ANY(0, (const double *)c->rhs_s, c->slot_stride, c->t1);
+        const double scale = 1.0;
+        if (c->sax.logL == 10) DCT_COLS_10();
+        else if (c->sax.logL == 9) DCT_COLS(1024, 9);
+        else if (c->sax.logL < 10) DCT_COLS(1024, 0);
+        else if (c->sax.logL == 11) DCT_COLS(2048, 11);
+        else DCT_COLS(4096, 0);
+    }
+    for (int j = 0; j <= n_enq; ++j) {
+        // y_j lives in cg_p[j & 1] (y_{j+1} overwrites y_{j-1}), b~ in c->r
+        ChebSweepArgs a{c->r, c->r, c->cg_p[j & 1], c->cg_p[(j + 1) & 1], c->cg_p[(j + 1) & 1], c->x, c->x0g, c->D_s, c->slot_stride,
+                        j == 0 ? c->gpart : c->gpart2, j, scale};
+#define CHEB_ROWS(C_, LG_)                                                                                             \
+    do {                                                                                                               \
+        const int rpw = 2 * (C_ >> c->fax.logL);                                                                       \
+        LAUNCHC((j == 0 ? PC_CHEB_ROWS0 : PC_CHEB_ROWS), (k_cheb_rows<C_, LG_>), dim3((ns + rpw - 1) / rpw, 1, c->B),  \
+                dim3(FftThreads<C_, LG_>::T), G, c->fax, a, (const double *)c->t2, c->t1, (const TrajState *)c->st);   \
+    } while (0)
+        if (c->fax.logL == 10) CHEB_ROWS(1024, 10);
+        else if (c->fax.logL == 9) CHEB_ROWS(1024, 9);
+        else if (c->fax.logL < 10) CHEB_ROWS(1024, 0);
+        else if (c->fax.logL == 11) CHEB_ROWS(2048, 11);
+        else CHEB_ROWS(4096, 0);
+        if (j < n_enq) {   // E_cols, m / P(m), E_cols of E_rows(Delta y_{j+1}) for the trajectories that go on to sweep j + 1
+            SpecArgs sp{c0, 0.0, 1.0, c2, c->ms, c->mf, nullptr, c->D_s, c->slot_stride, c->gpart, c->gpart2, 1};
+            const int gate = 16 + j + 1;
+            const double scale = 1.0;
+            if (c->sax.logL == 10) DCT_COLS_10();
+            else if (c->sax.logL == 9) DCT_COLS(1024, 9);
+            else if (c->sax.logL < 10) DCT_COLS(1024, 0);
+            else if (c->sax.logL == 11) DCT_COLS(2048, 11);
+            else DCT_COLS(4096, 0);
+        }
+    }
+    return 0;
+}
+
 // After schur_solve: dphi -> c->xf, dmu = 2 (K dphi + R_phi), step ceiling, start of the Armijo loop (F2:377-396).
 static int dmu_ceiling(vch2d_ctx *c, int strict) {
     const bool spectral = c->use_fft && !c->half_f && !c->half_s;
-    if (spectral && c->cg_last >= 0) {
-        const int last = c->cg_last, rd = last & 1;
-        FinSolveArgs f{c->gpart, c->gpart2, c->gpart3 + (size_t)rd * c->B * c->gnblk, c->gnblk, last >= 1 ? 1 : 0, rd, c->lin_maxit,
-                       c->cg_p[last & 1]};
+    const ChebFin nocheb{-1, 0, nullptr, nullptr};
+    if (spectral && c->cheb_enq >= 0) {
+        FinSolveArgs f{c->gpart, c->gpart2, c->gpart3, c->gnblk, 0, 0, c->lin_maxit, c->cg_p[0], c->cheb_enq};
         LAUNCH(k_dmu_ceiling_fin, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, (const double *)c->x, f, (const double *)c->phi_s,
                (const double *)c->D_s, (const double *)c->Rphi_s, c->dmu, c->xf, c->part,
                c->guess_wr >= 0 ? c->dprev[c->guess_wr] : (double *)nullptr,
                (c->guess_wr >= 0 && c->guess2_on) ? c->dprev2[c->guess_wr] : (double *)nullptr);
-        LAUNCH(k_fin_ceiling, dim3(c->B), dim3(64), c->st, c->part, c->nblk, strict, rd ^ 1);
+        LAUNCH(k_fin_ceiling, dim3(c->B), dim3(64), c->st, c->part, c->nblk, strict, -1,
+               ChebFin{c->cheb_enq, c->gnblk, c->gpart, c->gpart2});
+    } else if (spectral && c->cg_last >= 0) {
+        const int last = c->cg_last, rd = last & 1;
+        FinSolveArgs f{c->gpart, c->gpart2, c->gpart3 + (size_t)rd * c->B * c->gnblk, c->gnblk, last >= 1 ? 1 : 0, rd, c->lin_maxit,
+                       c->cg_p[last & 1], -1};
+        LAUNCH(k_dmu_ceiling_fin, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, (const double *)c->x, f, (const double *)c->phi_s,
+               (const double *)c->D_s, (const double *)c->Rphi_s, c->dmu, c->xf, c->part,
+               c->guess_wr >= 0 ? c->dprev[c->guess_wr] : (double *)nullptr,
+               (c->guess_wr >= 0 && c->guess2_on) ? c->dprev2[c->guess_wr] : (double *)nullptr);
+        LAUNCH(k_fin_ceiling, dim3(c->B), dim3(64), c->st, c->part, c->nblk, strict, rd ^ 1, nocheb);
     } else {
         LAUNCH(k_dmu_ceiling, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->x, c->phi_s, c->D_s, c->Rphi_s, c->dmu, c->xf,
                c->part);
-        LAUNCH(k_fin_ceiling, dim3(c->B), dim3(64), c->st, c->part, c->nblk, strict, -1);
+        LAUNCH(k_fin_ceiling, dim3(c->B), dim3(64), c->st, c->part, c->nblk, strict, -1, nocheb);
     }
     c->cg_last = -1;
+    c->cheb_enq = -1;
     return 0;
 }
 
@@ -815,9 +889,12 @@ static int newton_level(vch2d_ctx *c, double dt, const double *un, const double 
     }
     LAUNCH((k_fin_residual<0>), dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->hist_dev, c->P.kappa, dt, c->lin_tol, eta_,
            guess ? 1 : 0);
+    // form of this step's solves: reduction-free where the previous step's plans were short (forward_core decides)
+    const bool cheb = in_march && c->cheb_step && c->lin_eta > 0.0;
     if (c->spec) {
         for (int s = 0; s < c->spec_slots; ++s) {
-            VCHCHK(schur_solve(c, dt, c->spec_cgb[s], false));
+            if (cheb) VCHCHK(cheb_solve(c, dt, c->spec_chn[s]));
+            else VCHCHK(schur_solve(c, dt, c->spec_cgb[s], false));
             VCHCHK(dmu_ceiling(c, 1));
             // the trial of slot 0 is the one a second solve normally follows; a trajectory whose second solve comes later
             // (a rejected trial, a first solve that did not fit its slot) starts it from zero
@@ -838,14 +915,23 @@ static int newton_level(vch2d_ctx *c, double dt, const double *un, const double 
     };
     if (getenv("VCH_DEBUG_GUESS")) {
         const TrajState &S = c->st_host[0];
-        fprintf(stderr, "guess order %d / %d (run %d) | traj 0: ratio %.3e / %.3e solves %d sweeps %d %d %d normR %.3e active %d\n",
+        fprintf(stderr, "guess order %d / %d (run %d) | traj 0: ratio %.3e / %.3e solves %d sweeps %d %d %d normR %.3e active %d "
+                "tol %.3e %.3e %.3e kT %.6f %.6f %.6f\n",
                 c->guess_used, c->guess_used2, c->guess_run2, S.guess_ratio, S.guess_ratio2, S.step_solves, S.step_lin[0],
-                S.step_lin[1], S.step_lin[2], S.normR, S.newton_active);
+                S.step_lin[1], S.step_lin[2], S.normR, S.newton_active, S.step_tol[0], S.step_tol[1], S.step_tol[2],
+                S.step_kT[0], S.step_kT[1], S.step_kT[2]);
     }
     int guard = 0;
     while (any_active()) {
         if (++guard > NEWTON_MAXIT + 2) return vch_fail(VCH_ERR_STATE, "newton_level: state machine did not terminate");
-        VCHCHK(schur_solve(c, dt, cg_budget(c, true), true));
+        if (cheb) {        // the plans of the pending solves are in the state the host has just read
+            int need = 0;
+            for (int b = 0; b < c->B; ++b)
+                if (c->st_host[b].newton_active && c->st_host[b].lin_active) need = std::max(need, c->st_host[b].cheb_n);
+            VCHCHK(cheb_solve(c, dt, need));
+        } else {
+            VCHCHK(schur_solve(c, dt, cg_budget(c, true), true));
+        }
         VCHCHK(dmu_ceiling(c, 0));
         int tguard = 0;
         const bool trial_guess_ = true;
@@ -868,11 +954,28 @@ static int newton_level(vch2d_ctx *c, double dt, const double *un, const double 
             bound = std::max(bound, S.lin_budget);
         }
         c->spec_slots = std::min(solves, 4);
-        for (int s = 0; s < 4; ++s) {
-            // a slot this step did not use is sized like the longest solve seen
-            const int want = (s < solves ? sweeps[s] : longest) + 1;
-            c->spec_cgb[s] = std::max(2, std::min(std::min(want, bound), 64));
+        if (!cheb)
+            for (int s = 0; s < 4; ++s) {
+                // a slot this step did not use is sized like the longest solve seen
+                const int want = (s < solves ? sweeps[s] : longest) + 1;
+                c->spec_cgb[s] = std::max(2, std::min(std::min(want, bound), 64));
+            }
+    }
+    {
+        int solves = 1;
+        for (int b = 0; b < c->B; ++b)
+            if (!c->st_host[b].frozen) solves = std::max(solves, c->st_host[b].step_solves);
+        // the Chebyshev plans of this step's solves (known whichever form ran): the next step's solves are enqueued with
+        // what these asked for + the margin, and take the reduction-free form while no plan is longer than cheb_max
+        int chn[4] = {0, 0, 0, 0}, chmax = 0;
+        for (int b = 0; b < c->B; ++b) {
+            const TrajState &S = c->st_host[b];
+            if (S.frozen) continue;
+            for (int s = 0; s < 4 && s < S.step_solves; ++s) chn[s] = std::max(chn[s], S.step_chn[s]);
         }
+        for (int s = 0; s < 4 && s < solves; ++s) chmax = std::max(chmax, chn[s]);
+        for (int s = 0; s < 4; ++s) c->spec_chn[s] = (s < solves ? chn[s] : chmax) + c->cheb_margin;
+        c->cheb_step = c->cheb_on && c->use_fft && !c->half_f && !c->half_s && chmax <= c->cheb_max;
     }
     return 0;
 }
@@ -1212,6 +1315,7 @@ static int forward_core(vch2d_ctx *c, const double *u_dev, int u_rows, const dou
     c->guess_pol.reset();
     c->guess_pol2.reset();
     c->guess_run2 = 0;
+    c->cheb_step = false;             // the first step of a march has no plans to go by: CG form
     for (int step = 0; step < M; ++step) {
         const double *un = nullptr, *unp1 = nullptr;
         if (u_dev && step < u_rows - 1) {        // F2:545-548

@@ -636,6 +636,8 @@ struct FinSolveArgs {
     const double *gpart, *gpart2, *gpart3_rd;
     int gnblk, direct, rd, maxit;
     const double *p_last;                 // the direction of the last sweep
+    int cheb_enq;                         // >= 0: after a Chebyshev solve with that many sweeps enqueued (x is final: no
+                                          // reduction point to resolve; a trajectory whose plan asked for more has no x yet)
 };
 __global__ __launch_bounds__(NTH) void k_dmu_ceiling_fin(Geom G, Phys P, TrajState *__restrict__ st, long slot_stride,
                                                          const double *__restrict__ x, FinSolveArgs f,
@@ -655,7 +657,9 @@ __global__ __launch_bounds__(NTH) void k_dmu_ceiling_fin(Geom G, Phys P, TrajSta
     const long pb = b * G.plane;
     const int slot = st[b].slot;
     double alpha = 0.0;
-    if (st[b].lin_active) {
+    if (f.cheb_enq >= 0) {
+        if (st[b].lin_active && st[b].cheb_n > f.cheb_enq) return;
+    } else if (st[b].lin_active) {
         if (!st[b].ci_active[f.rd]) {                      // converged in an earlier sweep: its last step is in x already
             if (blk == 0 && threadIdx.x == 0) st[b].ci_active[f.rd ^ 1] = 0;
         } else {
@@ -859,6 +863,191 @@ __global__ __launch_bounds__((FftThreads<C, LOGL>::T)) void k_cg_rows_fwd(Geom G
             double tot = 0.0;
             for (int w = 0; w < T / 64; ++w) tot += sred[w];
             a.gpart3[((long)wr * a.nbatch + b) * gridDim.x + blockIdx.x] = tot;
+        }
+    }
+}
+
+// =====================================================================================================
+// Reduction-free (Chebyshev) forward solve, power-of-two grids.  spec(P^-1 A) lies in [1, kT] with kT known before the
+// solve (cg_setup), so the Chebyshev semi-iteration needs no inner product: its coefficients and its length follow from
+// the bound (cheb_plan).  In the three-term form on y (x = x0 + y, b~ = P^-1 rhs, y_0 = 0):
+//       y_1 = b~ / theta,      z_j = b~ - y_j - (P^-1 M)(Delta y_j),      y_{j+1} = y_j + c_j (y_j - y_{j-1}) + e_j z_j
+// With nothing to wait for between the inverse row transform of sweep j and the forward row transform of sweep j + 1,
+// the two are ONE kernel on the same rows (two in-LDS transforms back to back, as in k_dct_cols):
+//   [k_dct_rows<0>]   E_rows(rhs)                                    }  once per solve
+//   [k_dct_cols]      E_cols, multiplier 1 / P(m), E_cols            }
+//   [k_cheb_rows j=0] b~ = E_rows(.), y_1 = b~ / theta, E_rows(Delta y_1)
+//   [k_dct_cols]      E_cols, multiplier m / P(m), E_cols            }  per sweep: 2 launches, 72 B per node
+//   [k_cheb_rows j]   g = E_rows(.), z_j, y_{j+1}, E_rows(Delta y_{j+1})  }  (CG form: 3 launches, 120 B)
+// A trajectory's LAST kernel (j = its cheb_n) stores x = x0 + y_{j+1} and transforms nothing; later kernels of the
+// launch sequence skip it.  Each kernel leaves the partial of <z_j,z_j>_Z behind (one sweep late, for the books only).
+// =====================================================================================================
+struct ChebSweepArgs {
+    const double *bt_in;                  // b~ [B][plane], read by the sweeps j >= 1
+    double *bt_out;                       // ... written by sweep 0
+    const double *y_cur, *y_prev;         // y_j, y_{j-1} (j >= 2)
+    double *y_new;                        // y_{j+1}: may be the buffer of y_{j-1} (same node, read before written)
+    double *x_out;                        // the finished increment of a trajectory's last sweep
+    const double *x0;                     // starting guess of a primed solve (TrajState::x_primed) or NULL
+    const double *Dslot;                  // slot-indexed D planes
+    long d_slot_stride;
+    double *gpart;                        // [B][gridDim.x] partials of <z_j,z_j>_Z
+    int j;
+    double scale;                         // 1 / (4 Nf Ns) of the transform pair
+};
+
+template <int C, int LOGL>
+__global__ __launch_bounds__((FftThreads<C, LOGL>::T)) void k_cheb_rows(Geom G, FftAxis ax, ChebSweepArgs a, const double *__restrict__ in,
+                                                                       double *__restrict__ out, const TrajState *__restrict__ st) {
+    const int b = blockIdx.z;
+    if (!st[b].lin_active || a.j > st[b].cheb_n) return;
+    const bool last = a.j == st[b].cheb_n;
+    __shared__ double2 buf[FftLds<C>::SIZE];
+    constexpr int T = FftThreads<C, LOGL>::T;
+    const int tid = threadIdx.x;
+    const int logL = LOGL ? LOGL : ax.logL, L = 1 << logL, N = L >> 1, nfft = C >> logL;
+    const int row0 = blockIdx.x * 2 * nfft, n1 = N + 1;
+    const long pb = b * G.plane;
+    // coefficients of this sweep: e_j = 2 rho_j / delta = 2 / (2 theta - delta rho_{j-1}), c_j = rho_j rho_{j-1}
+    const double theta = st[b].cheb_theta, delta = st[b].cheb_delta;
+    double cj = 0.0, ej = 1.0 / theta;
+    {
+        double rho_prev = delta / theta;
+        for (int i = 1; i <= a.j; ++i) {
+            ej = 2.0 / (2.0 * theta - delta * rho_prev);
+            const double rho = 0.5 * delta * ej;
+            cj = rho * rho_prev;
+            rho_prev = rho;
+        }
+    }
+    const double dbar = st[b].dbar;
+    const double *Dp = a.Dslot + st[b].slot * a.d_slot_stride + pb;
+    const bool primed = a.x0 && st[b].x_primed;
+    const bool need_norm = !(last && a.j == 0);            // a solve without sweeps keeps no books
+    double acc = 0.0;
+    // node (row, k): g = the transform's output there; returns Delta y_{j+1}, the next transform's input
+    auto upd = [&](int row, int k, double g) -> double {
+        const long o = (long)row * G.pitch + k;
+        const double gg = a.scale * g;
+        double z, yn, dl = 0.0;
+        if (need_norm || !last) dl = Dp[o] - dbar;
+        if (a.j == 0) {
+            z = gg;
+            yn = ej * z;
+            if (!last) a.bt_out[pb + o] = gg;
+        } else {
+            const double yc = a.y_cur[pb + o], yp = a.j >= 2 ? a.y_prev[pb + o] : 0.0;
+            z = a.bt_in[pb + o] - yc - gg;
+            yn = yc + cj * (yc - yp) + ej * z;
+        }
+        if (need_norm) acc += wdev(row, k, G) * dl * (z * z);
+        if (last) a.x_out[pb + o] = primed ? a.x0[pb + o] + yn : yn;
+        else a.y_new[pb + o] = yn;
+        return dl * yn;
+    };
+    const double *ib = in + pb;
+    double *ob = out + pb;
+    auto put = [&](int row, int k, double e) { ob[(long)row * G.pitch + k] = e; };
+    constexpr bool DIRECT = FFT_R8 && LOGL >= 9 && LOGL <= 11;
+    if (DIRECT) {
+        constexpr int LL = 1 << (LOGL ? LOGL : 1), LG = LOGL ? LOGL : 1;
+        struct RowIngest {
+            enum { ACTIVE = 1 };
+            const double *ib_;
+            long pitch_;
+            int row0_, ns_;
+            __device__ __forceinline__ double2 operator()(int idx) const {
+                const int f = idx >> LG, i = idx & (LL - 1), m = i <= LL / 2 ? i : LL - i;
+                const int ra = row0_ + 2 * f;
+                const double *p = ib_ + (long)ra * pitch_ + m;
+                return make_double2(ra < ns_ ? p[0] : 0.0, ra + 1 < ns_ ? p[pitch_] : 0.0);
+            }
+        };
+        // the first transform's last pass hands its outputs to the update; what the update returns goes back into the
+        // image as the even extension of the next transform's input (entry k and its mirror L - k from the same thread)
+        struct UpdEmit {
+            enum { ACTIVE = 1, TO_LDS = 1 };
+            decltype(upd) &upd_;
+            double2 *buf_;
+            int row0_, ns_;
+            bool last_;
+            __device__ __forceinline__ void operator()(int idx, double2 v) const {
+                const int f = idx >> LG, k = idx & (LL - 1);
+                if (k > LL / 2) return;
+                const int ra = row0_ + 2 * f;
+                double2 w = make_double2(0.0, 0.0);
+                if (ra < ns_) w.x = upd_(ra, k, v.x);
+                if (ra + 1 < ns_) w.y = upd_(ra + 1, k, v.y);
+                if (!last_) {
+                    buf_[swz<LOGL>(idx)] = w;
+                    if (k > 0 && k < LL / 2) buf_[swz<LOGL>(f * LL + LL - k)] = w;
+                }
+            }
+        };
+        struct RowEmit {
+            enum { ACTIVE = 1, TO_LDS = 0 };
+            decltype(put) &put_;
+            int row0_, ns_;
+            __device__ __forceinline__ void operator()(int idx, double2 v) const {
+                const int f = idx >> LG, k = idx & (LL - 1);
+                if (k <= LL / 2) {
+                    const int ra = row0_ + 2 * f;
+                    if (ra < ns_) put_(ra, k, v.x);
+                    if (ra + 1 < ns_) put_(ra + 1, k, v.y);
+                }
+            }
+        };
+        fft_lds<C, LOGL>(buf, ax, UpdEmit{upd, buf, row0, G.ns, last}, RowIngest{ib, (long)G.pitch, row0, G.ns});
+        if (!last) fft_lds<C, LOGL>(buf, ax, RowEmit{put, row0, G.ns});
+    } else {
+        const float inv_n1 = 1.0f / (float)n1;
+        for (int idx = tid; idx < nfft * n1; idx += T) {
+            const int f = nfft == 1 ? 0 : (int)(((float)idx + 0.5f) * inv_n1), j = idx - f * n1;
+            const int ra = row0 + 2 * f;
+            const double2 v = make_double2(ra < G.ns ? ib[(long)ra * G.pitch + j] : 0.0,
+                                           ra + 1 < G.ns ? ib[(long)(ra + 1) * G.pitch + j] : 0.0);
+            buf[swz<LOGL>(f * L + j)] = v;
+            if (j > 0 && j < N) buf[swz<LOGL>(f * L + L - j)] = v;
+        }
+        __syncthreads();
+        fft_lds<C, LOGL>(buf, ax);
+        // entry k <= N of a transform is read and rewritten by ONE thread, the entries above N are only written: no barrier
+        // between the reads and the writes of this loop
+        for (int idx = tid; idx < nfft * n1; idx += T) {
+            const int f = nfft == 1 ? 0 : (int)(((float)idx + 0.5f) * inv_n1), k = idx - f * n1;
+            const int ra = row0 + 2 * f;
+            const double2 v = buf[swz<LOGL>(f * L + k)];
+            double2 w = make_double2(0.0, 0.0);
+            if (ra < G.ns) w.x = upd(ra, k, v.x);
+            if (ra + 1 < G.ns) w.y = upd(ra + 1, k, v.y);
+            if (!last) {
+                buf[swz<LOGL>(f * L + k)] = w;
+                if (k > 0 && k < N) buf[swz<LOGL>(f * L + L - k)] = w;
+            }
+        }
+        if (!last) {
+            __syncthreads();
+            fft_lds<C, LOGL>(buf, ax);
+            for (int idx = tid; idx < 2 * nfft * n1; idx += T) {
+                const int rr = nfft == 1 ? (idx >= n1 ? 1 : 0) : (int)(((float)idx + 0.5f) * inv_n1), k = idx - rr * n1;
+                const int row = row0 + rr;
+                if (row < G.ns) {
+                    const double2 c = buf[swz<LOGL>((rr >> 1) * L + k)];
+                    put(row, k, (rr & 1) ? c.y : c.x);
+                }
+            }
+        }
+    }
+    if (need_norm) {
+        acc = wave_sum(acc);
+        __syncthreads();
+        double *sred = reinterpret_cast<double *>(buf);
+        if ((tid & 63) == 0) sred[tid >> 6] = acc;
+        __syncthreads();
+        if (tid == 0) {
+            double tot = 0.0;
+            for (int w = 0; w < T / 64; ++w) tot += sred[w];
+            a.gpart[(long)b * gridDim.x + blockIdx.x] = tot;
         }
     }
 }

@@ -31,6 +31,7 @@ struct TrajState {
     double best_norm, best_alpha;
     double Dmin, Dmax, dbar;   // range of the Jacobian diagonal, preconditioner shift
     double rho;                // bound of the CG contraction per iteration from the spectrum of P^-1 A (cg_setup)
+    double kT;                 // the bound of that spectrum itself: spec(P^-1 A) in [1, kT]
     long newton_total;         // residual norms recorded over the whole march
     // linear solve (preconditioned CG on the Schur system)
     int lin_active, lin_it;
@@ -53,6 +54,13 @@ struct TrajState {
     // per time step, for the host's launch schedule: linear solves started and the longest of them
     int step_solves, step_lin_max;
     int step_lin[4];           // sweeps of the first four solves of the step
+    double step_tol[4], step_kT[4];   // their relative tolerances and the bounds kappa_T of the spectrum of P^-1 A
+    int step_chn[4];           // ... and the sweeps a Chebyshev solve of them needs (cheb_plan), whichever solver ran
+    // reduction-free (Chebyshev) form of the forward solve (vch_fft.h, k_cheb_rows): spec(P^-1 A) in [theta - delta,
+    // theta + delta] = [1, kT] and the number of sweeps after which the rigorous bound 1 / T_{n+1}(theta/delta) is below
+    // the solve's tolerance -- all known before the solve starts, so no inner product steers it
+    int cheb_n, cheb_pad;
+    double cheb_theta, cheb_delta;
     int lin_took, lin_unconv;  // adjoint: this solve started (its y is valid); solves the enqueued sweeps did not finish
     int cg_pending, cg_pbuf, cg_pad;   // forward CG: step (alpha, p[cg_pbuf]) computed but not yet added to x
     // forward CG, per-iteration state in two copies: iteration k's stencil kernel derives the step of
@@ -68,7 +76,9 @@ struct TrajState {
 
 // gate codes of the preconditioner kernels: 1 = lin_active, 2 / 3 = copy 0 / 1 of the forward CG's per-iteration flag
 // 4 = the adjoint solve of this step took place (lin_took)
+// 16 + j = the column pass in front of sweep j of a Chebyshev solve (the trajectory is solving and needs that sweep)
 __device__ __forceinline__ bool gate_open(const TrajState &S, int gate) {
+    if (gate >= 16) return S.lin_active != 0 && gate - 16 <= S.cheb_n;
     return gate == 1 ? S.lin_active != 0 : (gate == 4 ? S.lin_took != 0 : S.ci_active[gate - 2] != 0);
 }
 
@@ -250,6 +260,7 @@ __device__ __forceinline__ void newton_begin(TrajState &S) {
     S.step_solves = 0;
     S.step_lin_max = 0;
     S.step_lin[0] = S.step_lin[1] = S.step_lin[2] = S.step_lin[3] = 0;
+    S.step_chn[0] = S.step_chn[1] = S.step_chn[2] = S.step_chn[3] = 0;
     S.x_primed = 0;
     S.lin_rscale = 1.0;
     S.guess_ratio = 1.0;
@@ -999,6 +1010,7 @@ __device__ __forceinline__ void cg_setup(TrajState &S, double g0, double cscale,
     double kT = den > 0.0 ? 1.0 + cscale * (S.Dmax - S.dbar) / den : 1e12;
     const double sq = sqrt(kT);
     const double rate = (sq - 1.0) / (sq + 1.0);
+    S.kT = kT;
     S.rho = rate;
     double k = rate > 1e-300 ? log(2.0 / tol) / -log(rate) : 1.0;
     S.lin_budget = (int)fmin(4000.0, ceil(k) + 2.0);
@@ -1016,6 +1028,43 @@ __device__ __forceinline__ double newton_lin_tol(double r0, double lin_tol, doub
     if (!(eta > 0.0) || !(r0 > 0.0)) return lin_tol;
     if (r0 > 1e8) return fmax(lin_tol, 1e-12);
     return fmin(fmax(lin_tol, eta / r0), 0.5);
+}
+
+// Chebyshev plan of a forward solve: with spec(P^-1 A) in [1, kT] (cg_setup) the iteration
+//     y_1 = b~ / theta,   y_{j+1} = y_j + rho_j rho_{j-1} (y_j - y_{j-1}) + (2 rho_j / delta) (b~ - P^-1 A y_j)
+// (b~ = P^-1 rhs, rho_0 = delta / theta, rho_j = 1 / (2 theta / delta - rho_{j-1})) leaves, in the norm the stop test of the
+// CG form uses, ||z_{n+1}||_Z <= ||z_0||_Z / T_{n+1}(theta / delta) after n sweeps: n is the smallest count for which that
+// bound is below the solve's tolerance.  The first iterate costs no sweep (the preconditioner application alone).
+constexpr int CHEB_NCAP = 200;
+__device__ __forceinline__ void cheb_plan(TrajState &S, double tol) {
+    const double kT = S.kT > 1.0 ? S.kT : 1.0;
+    S.cheb_theta = 0.5 * (kT + 1.0);
+    S.cheb_delta = 0.5 * (kT - 1.0);
+    int n = 0;
+    if (S.cheb_delta > 0.0) {
+        const double sigma = S.cheb_theta / S.cheb_delta;
+        double tkm1 = 1.0, tk = sigma;                       // T_0, T_1
+        while (n < CHEB_NCAP && !(1.0 / tk <= tol)) {
+            const double tn = 2.0 * sigma * tk - tkm1;
+            tkm1 = tk;
+            tk = tn;
+            ++n;
+        }
+    }
+    S.cheb_n = n;
+}
+// T_n(sigma) / T_{n+1}(sigma): what the bound promises for the last step of an n-sweep solve
+__device__ __forceinline__ double cheb_last_factor(double theta, double delta, int n) {
+    if (!(delta > 0.0)) return 0.0;
+    const double sigma = theta / delta;
+    double tkm1 = 1.0, tk = sigma;
+    for (int k = 0; k < n; ++k) {
+        const double tn = 2.0 * sigma * tk - tkm1;
+        tkm1 = tk;
+        tk = tn;
+        if (!(tk < 1e280)) return 1.0 / (2.0 * sigma);      // far in the asymptotic range
+    }
+    return tkm1 / tk;
 }
 
 template <int MODE>
@@ -1082,12 +1131,18 @@ __device__ __forceinline__ void fin_residual_update(TrajState &S, const double (
         else if (primed) S.guess_ratio2 = v[4] > 0.0 ? sqrt(v[1] / v[4]) : 1.0;
         S.lin_reltol = newton_lin_tol(S.lin_r0, lin_tol, eta);
         cg_setup(S, 2.0 * sqrt(0.5 * kappa / dt), 1.0, S.lin_reltol);
+        cheb_plan(S, S.lin_reltol);
         S.lin_active = 1;
         S.lin_it = 0;
         S.lin_prev = 1e300;
         S.lin_rel = 1.0;
         S.nsolves++;
         S.step_solves++;
+        if (S.step_solves <= 4) {
+            S.step_tol[S.step_solves - 1] = S.lin_reltol;
+            S.step_kT[S.step_solves - 1] = S.kT;
+            S.step_chn[S.step_solves - 1] = S.cheb_n;
+        }
         // (a zero right-hand side is not special-cased: the solve starts, zeroes x and ends at its first reduction point)
     } else {
         S.alpha *= 0.5;
@@ -1286,10 +1341,35 @@ __global__ void k_fin_cg_beta(TrajState *st, const double *__restrict__ part, in
 // next solve slot of the schedule -- or the host's continuation loop -- runs it again with the budget it needs.
 // fin_copy >= 0 (after k_dmu_ceiling_fin): the solve's last reduction point was resolved by that kernel into copy
 // fin_copy of the per-sweep state, from which lin_active is taken over here.
-__global__ void k_fin_ceiling(TrajState *st, const double *__restrict__ part, int nblk, int strict, int fin_copy) {
+// cheb.enq >= 0 (after a Chebyshev solve with cheb.enq sweeps enqueued): a trajectory whose plan asked for more sweeps has
+// not finished (it is left as it is, like an unfinished CG solve under `strict`); for the others the solve's books are
+// closed here: sweeps done, and the relative residual the solve left, estimated as the last directly summed
+// ||z_n||_Z / ||z_0||_Z (partials of k_cheb_rows) times the factor T_n / T_{n+1} the bound promises for the last step.
+struct ChebFin {
+    int enq, gnblk;
+    const double *g0, *gn;                  // [B][gnblk] partials of <z_0,z_0>_Z and of <z_n,z_n>_Z
+};
+__global__ void k_fin_ceiling(TrajState *st, const double *__restrict__ part, int nblk, int strict, int fin_copy, ChebFin cheb) {
     const int b = blockIdx.x;
     TrajState S = st[b];                    // in registers, written back once (see k_fin_residual)
     if (!S.newton_active || S.need_trial) return;
+    if (cheb.enq >= 0 && S.lin_active) {
+        if (S.cheb_n > cheb.enq) return;    // unfinished: taken up again by the next solve slot / the host's loop
+        double rel = 1.0;
+        if (S.cheb_n >= 1) {
+            const double g0 = fin_sum1(cheb.g0, cheb.gnblk, b, 1, 0), gn = fin_sum1(cheb.gn, cheb.gnblk, b, 1, 0);
+            rel = g0 > 0.0 ? sqrt(fmax(gn, 0.0) / g0) : 0.0;
+        }
+        rel *= cheb_last_factor(S.cheb_theta, S.cheb_delta, S.cheb_n);
+        S.lin_rel = rel;
+        S.lin_it = S.cheb_n;
+        S.lin_total += S.cheb_n;
+        if (rel * S.lin_rscale > S.lin_maxrel) S.lin_maxrel = rel * S.lin_rscale;
+        S.lin_maxabs = fmax(S.lin_maxabs, rel * S.lin_r0);
+        if (S.cheb_n > S.step_lin_max) S.step_lin_max = S.cheb_n;
+        if (S.step_solves >= 1 && S.step_solves <= 4) S.step_lin[S.step_solves - 1] = S.cheb_n;
+        S.lin_active = 0;
+    }
     if (fin_copy >= 0 && S.lin_active) {
         S.lin_active = fin_copy == 0 ? S.ci_active[0] : S.ci_active[1];
         if (strict && S.lin_active) {       // unfinished: only the flag goes back
