@@ -450,11 +450,26 @@ def build_targets(x, t_hist, phi_initial, Lx, T, choice_t=1, choice_q=1, A_T=0.7
     return phi_T, phi_Q
 
 
+def error_metrics(phi_hist, phi_Q, phi_T, x, t_hist):
+    """Relative tracking / terminal errors of the driver loop, G1:425-450: space-time L2 of phi - phi_Q (trapezoid in x
+    per level, then in t) over that of phi_Q -- replaced by the RMS scale sqrt(|Omega| T) when the target is ~0 -- and
+    the L2 of phi(T) - phi_T over that of phi_T, each denominator + 1e-12."""
+    l2xt = lambda a: float(np.sqrt(_trapz(_trapz(a ** 2, x, 1), t_hist)))
+    l2x = lambda a: float(np.sqrt(_trapz(a ** 2, x)))
+    rms = float(np.sqrt(max(float(x[-1] - x[0]), 1e-30) * max(float(t_hist[-1] - t_hist[0]), 1e-30)))
+    den = l2xt(phi_Q)
+    if den < 1e-9 * rms:
+        den = rms
+    return l2xt(phi_hist - phi_Q) / (den + 1e-12), l2x(phi_hist[-1] - phi_T) / (l2x(phi_T) + 1e-12)
+
+
 @dataclass
 class PGDResult:
     costs: list = field(default_factory=list)
     alphas: list = field(default_factory=list)
     trials: list = field(default_factory=list)
+    tracking: list = field(default_factory=list)
+    terminal: list = field(default_factory=list)
     u: np.ndarray = None
     phi: np.ndarray = None
     r: np.ndarray = None
@@ -496,6 +511,8 @@ def pgd(P: Params1D, O: OptParams1D, n_iter=None, choice_t=1, choice_q=1, solver
                 alpha *= 0.8
             a_k = alpha
         res.costs.append(c_n); res.alphas.append(a_k); res.trials.append(nt)
+        e1, e2 = error_metrics(phi_n, phi_Q, phi_T, x, t_hist)
+        res.tracking.append(e1); res.terminal.append(e2)
         if k > 0 and abs(res.costs[-1] - res.costs[-2]) < 1e-7:
             plateau += 1
         else:

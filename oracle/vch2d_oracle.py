@@ -515,6 +515,8 @@ class PGDResult:
     alphas: list = field(default_factory=list)
     attempts: list = field(default_factory=list)
     changes: list = field(default_factory=list)
+    tracking: list = field(default_factory=list)
+    terminal: list = field(default_factory=list)
     u: np.ndarray = None
     phi: np.ndarray = None
     r: np.ndarray = None
@@ -537,7 +539,7 @@ def line_search(u_k, cost_k, g, phi_Q, phi_T, x, y, P, O, alpha_init, fwd, beta=
     return alpha, u_n, c_n, phi_n, t_n, att
 
 
-def pgd(P: Params2D, O: OptParams, n_iter=None, seed=42, amp=0.1, choice_t=1, choice_q=1):
+def pgd(P: Params2D, O: OptParams, n_iter=None, seed=42, amp=0.1, choice_t=1, choice_q=1, zero_target_q=False):
     """The loop of G2:291-382 (optimistic step with alpha_prev, backtracking from
     0.8*alpha_prev, alpha growth 1.2 / plateau 1.5 after 5 its |dJ|<1e-5, stop when the
     relative control change < 1e-5 and k > 20)."""
@@ -545,6 +547,8 @@ def pgd(P: Params2D, O: OptParams, n_iter=None, seed=42, amp=0.1, choice_t=1, ch
     phi_k, (x, y), t_k = fwd(None)
     u_k = np.zeros_like(phi_k)
     phi_T, phi_Q = build_targets(x, y, t_k, phi_k[0].copy(), P.Lx, P.Ly, P.T, choice_t, choice_q)
+    if zero_target_q:                  # tests: the RMS fallback of the tracking error (G2:353-354)
+        phi_Q = np.zeros_like(phi_Q)
     cost_k = cost(phi_k, u_k, phi_Q, phi_T, x, y, t_k, O)
     res = PGDResult(costs=[cost_k])
     alpha_prev, plateau = O.alpha_max, 0
@@ -561,6 +565,8 @@ def pgd(P: Params2D, O: OptParams, n_iter=None, seed=42, amp=0.1, choice_t=1, ch
             a_k, u_n, c_n, phi_n, t_n, att = line_search(u_k, cost_k, g, phi_Q, phi_T, x, y, P, O,
                                                          alpha_prev * 0.8, fwd)
         res.costs.append(c_n); res.alphas.append(a_k); res.attempts.append(att)
+        e1, e2 = error_metrics(phi_n, phi_Q, phi_T, x, y, t_k)
+        res.tracking.append(e1); res.terminal.append(e2)
         if k > 0 and abs(res.costs[-1] - res.costs[-2]) < 1e-5:
             plateau += 1
         else:

@@ -782,8 +782,10 @@ static int cheb_solve(vch2d_ctx *c, double dt, int n_enq) {
     }
     for (int j = 0; j <= n_enq; ++j) {
         // y_j lives in cg_p[j & 1] (y_{j+1} overwrites y_{j-1}), b~ in c->r
-        ChebSweepArgs a{c->r, c->r, c->cg_p[j & 1], c->cg_p[(j + 1) & 1], c->cg_p[(j + 1) & 1], c->x, c->x0g, c->D_s, c->slot_stride,
-                        j == 0 ? c->gpart : c->gpart2, j, scale};
+        ChebSweepArgs a{c->r, c->r, c->cg_p[j & 1], c->cg_p[(j + 1) & 1], c->cg_p[(j + 1) & 1], c->xf, c->x0g, c->D_s, c->slot_stride,
+                        j == 0 ? c->gpart : c->gpart2, j, scale, c->phi_s, c->gpart3,
+                        c->guess_wr >= 0 ? c->dprev[c->guess_wr] : (double *)nullptr,
+                        (c->guess_wr >= 0 && c->guess2_on) ? c->dprev2[c->guess_wr] : (double *)nullptr};
 #define CHEB_ROWS(C_, LG_)                                                                                             \
     do {                                                                                                               \
         const int rpw = 2 * (C_ >> c->fax.logL);                                                                       \
@@ -812,15 +814,12 @@ static int cheb_solve(vch2d_ctx *c, double dt, int n_enq) {
 // After schur_solve: dphi -> c->xf, dmu = 2 (K dphi + R_phi), step ceiling, start of the Armijo loop (F2:377-396).
 static int dmu_ceiling(vch2d_ctx *c, int strict) {
     const bool spectral = c->use_fft && !c->half_f && !c->half_s;
-    const ChebFin nocheb{-1, 0, nullptr, nullptr};
+    const ChebFin nocheb{-1, 0, nullptr, nullptr, nullptr};
     if (spectral && c->cheb_enq >= 0) {
-        FinSolveArgs f{c->gpart, c->gpart2, c->gpart3, c->gnblk, 0, 0, c->lin_maxit, c->cg_p[0], c->cheb_enq};
-        LAUNCH(k_dmu_ceiling_fin, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, (const double *)c->x, f, (const double *)c->phi_s,
-               (const double *)c->D_s, (const double *)c->Rphi_s, c->dmu, c->xf, c->part,
-               c->guess_wr >= 0 ? c->dprev[c->guess_wr] : (double *)nullptr,
-               (c->guess_wr >= 0 && c->guess2_on) ? c->dprev2[c->guess_wr] : (double *)nullptr);
+        // the solve's last row kernel has stored dphi (c->xf), kept it for the guesses and taken the ceiling ratios; the
+        // trial kernel (k_residual2) does the back substitution itself
         LAUNCH(k_fin_ceiling, dim3(c->B), dim3(64), c->st, c->part, c->nblk, strict, -1,
-               ChebFin{c->cheb_enq, c->gnblk, c->gpart, c->gpart2});
+               ChebFin{c->cheb_enq, c->gnblk, c->gpart, c->gpart2, c->gpart3});
     } else if (spectral && c->cg_last >= 0) {
         const int last = c->cg_last, rd = last & 1;
         FinSolveArgs f{c->gpart, c->gpart2, c->gpart3 + (size_t)rd * c->B * c->gnblk, c->gnblk, last >= 1 ? 1 : 0, rd, c->lin_maxit,
@@ -842,8 +841,12 @@ static int dmu_ceiling(vch2d_ctx *c, int strict) {
 
 #define RESIDUAL_TRIAL()                                                                                                    \
     do {                                                                                                                    \
-        LAUNCHC(PC_RESIDUAL, (k_residual<1>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s,     \
-                c->Rphi_s, c->rhs_s, c->D_s, c->mu0, c->xf, c->dmu, c->cphi, c->cmu, dt, c->part);                          \
+        if (cheb)                                                                                                           \
+            LAUNCHC(PC_RESIDUAL, k_residual2, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s,     \
+                    c->Rphi_s, c->rhs_s, c->D_s, (const double *)c->xf, c->cphi, c->cmu, dt, c->part);                      \
+        else                                                                                                                \
+            LAUNCHC(PC_RESIDUAL, (k_residual<1>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s, \
+                    c->Rphi_s, c->rhs_s, c->D_s, c->mu0, c->xf, c->dmu, c->cphi, c->cmu, dt, c->part);                      \
         if (guess2 && trial_guess_)                                                                                         \
             LAUNCHC(PC_GUESS, k_guess, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, ga2, (const double *)c->D_s,  \
                     dt, c->rhs_s, c->x0g, c->part, 1);                                                                      \

@@ -894,6 +894,11 @@ struct ChebSweepArgs {
     double *gpart;                        // [B][gridDim.x] partials of <z_j,z_j>_Z
     int j;
     double scale;                         // 1 / (4 Nf Ns) of the transform pair
+    // a trajectory's last sweep also takes the step ceiling (F2:381-387: min over the nodes of (+-(1 - delta) - phi) / dphi,
+    // per-workgroup minima into cmin) and keeps the step's first / second Newton increment for the next steps' guesses
+    const double *phi_s;                  // slot-indexed iterate
+    double *cmin;                         // [B][gridDim.x]
+    double *keep1, *keep2;                // ring planes of this step (or NULL)
 };
 
 template <int C, int LOGL>
@@ -924,7 +929,9 @@ __global__ __launch_bounds__((FftThreads<C, LOGL>::T)) void k_cheb_rows(Geom G, 
     const double *Dp = a.Dslot + st[b].slot * a.d_slot_stride + pb;
     const bool primed = a.x0 && st[b].x_primed;
     const bool need_norm = !(last && a.j == 0);            // a solve without sweeps keeps no books
-    double acc = 0.0;
+    double acc = 0.0, cmin = 1e300;
+    const double *php = a.phi_s + st[b].slot * a.d_slot_stride + pb;
+    double *const keepp = st[b].iters == 1 ? a.keep1 : (st[b].iters == 2 ? a.keep2 : nullptr);
     // node (row, k): g = the transform's output there; returns Delta y_{j+1}, the next transform's input
     auto upd = [&](int row, int k, double g) -> double {
         const long o = (long)row * G.pitch + k;
@@ -941,8 +948,15 @@ __global__ __launch_bounds__((FftThreads<C, LOGL>::T)) void k_cheb_rows(Geom G, 
             yn = yc + cj * (yc - yp) + ej * z;
         }
         if (need_norm) acc += wdev(row, k, G) * dl * (z * z);
-        if (last) a.x_out[pb + o] = primed ? a.x0[pb + o] + yn : yn;
-        else a.y_new[pb + o] = yn;
+        if (last) {
+            const double d = primed ? a.x0[pb + o] + yn : yn, ph = php[o];
+            a.x_out[pb + o] = d;
+            if (keepp) keepp[pb + o] = d;
+            if (d > 0.0) cmin = fmin(cmin, (1.0 - DELTA_SEP - ph) / d);
+            else if (d < 0.0) cmin = fmin(cmin, (-1.0 + DELTA_SEP - ph) / d);
+        } else {
+            a.y_new[pb + o] = yn;
+        }
         return dl * yn;
     };
     const double *ib = in + pb;
@@ -1038,16 +1052,24 @@ __global__ __launch_bounds__((FftThreads<C, LOGL>::T)) void k_cheb_rows(Geom G, 
             }
         }
     }
-    if (need_norm) {
+    if (need_norm || last) {
         acc = wave_sum(acc);
+        cmin = wave_min(cmin);
         __syncthreads();
         double *sred = reinterpret_cast<double *>(buf);
-        if ((tid & 63) == 0) sred[tid >> 6] = acc;
+        if ((tid & 63) == 0) {
+            sred[tid >> 6] = acc;
+            sred[T / 64 + (tid >> 6)] = cmin;
+        }
         __syncthreads();
         if (tid == 0) {
-            double tot = 0.0;
-            for (int w = 0; w < T / 64; ++w) tot += sred[w];
-            a.gpart[(long)b * gridDim.x + blockIdx.x] = tot;
+            double tot = 0.0, mn = 1e300;
+            for (int w = 0; w < T / 64; ++w) {
+                tot += sred[w];
+                mn = fmin(mn, sred[T / 64 + w]);
+            }
+            if (need_norm) a.gpart[(long)b * gridDim.x + blockIdx.x] = tot;
+            if (last) a.cmin[(long)b * gridDim.x + blockIdx.x] = mn;
         }
     }
 }

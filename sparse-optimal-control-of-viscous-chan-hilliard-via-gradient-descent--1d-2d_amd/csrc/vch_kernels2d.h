@@ -388,6 +388,93 @@ __global__ __launch_bounds__(NTH) void k_residual(Geom G, Phys P, const TrajStat
     block_reduce_store<4>(acc, op, sred, part + ((long)b * nblk + blk) * NPART);
 }
 
+// The trial form for the reduction-free solves (cheb_solve): the back substitution dmu = 2 (K dphi + R_phi) (F2:241-253,
+// second block row) happens HERE, on the haloed tile, from dphi, D and R_phi of the current iterate -- no kernel between
+// the solve and the trial writes dmu (the step ceiling is taken by the solve's last row kernel, k_cheb_rows).  Same
+// arithmetic, in the same order, as k_dmu_ceiling followed by k_residual<1>: bit-identical results.
+// LDS: phi_t and dphi with halo 2, and ONE halo-1 buffer that holds mu_t first and R_phi afterwards (R_phi at a node needs
+// mu_t at that node only, so it is formed in place once the Laplacians of mu_t have been taken).
+__global__ __launch_bounds__(NTH) void k_residual2(Geom G, Phys P, const TrajState *__restrict__ st, long slot_stride,
+                                                   double *__restrict__ phi_s, double *__restrict__ mu_s,
+                                                   double *__restrict__ Rphi_s, double *__restrict__ rhs_s,
+                                                   double *__restrict__ D_s, const double *__restrict__ dphi,
+                                                   const double *__restrict__ cphi, const double *__restrict__ cmu, double dt,
+                                                   double *__restrict__ part) {
+    TILE_COORDS;
+    const TrajState S = st[b];
+    if (!S.newton_active || !S.need_trial) return;
+    __shared__ double sp[(TY + 4) * (TX + 4)];
+    __shared__ double sd[(TY + 4) * (TX + 4)];
+    __shared__ double sm[(TY + 2) * (TX + 2)];
+    __shared__ double sred[NPART * 4];
+    constexpr int W2 = TX + 4, W1 = TX + 2;
+    const long pb = b * G.plane;
+    const int src = S.slot, dst = 1 - S.slot;
+    const double *phi_o = phi_s + src * slot_stride + pb, *mu_o = mu_s + src * slot_stride + pb;
+    const double *D_o = D_s + src * slot_stride + pb, *R_o = Rphi_s + src * slot_stride + pb;
+    for (int e = threadIdx.x; e < W2 * (TY + 4); e += NTH) {
+        int ly = e / W2, lxx = e - ly * W2;
+        int gr = refl(r0 - 2 + ly, G.ns), gc = refl(c0 - 2 + lxx, G.nf);
+        long o = (long)gr * G.pitch + gc;
+        const double d = dphi[pb + o];
+        sd[e] = d;
+        sp[e] = phi_o[o] + S.alpha * d;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < (TY + 2) * W1; e += NTH) {
+        int ly = e / W1, lxx = e - ly * W1;
+        int gr = refl(r0 - 1 + ly, G.ns), gc = refl(c0 - 1 + lxx, G.nf);
+        int p2 = (ly + 1) * W2 + lxx + 1;
+        long o = (long)gr * G.pitch + gc;
+        const double dm = 2.0 * ((-0.5 * P.kappa * lap_at<W2>(sd, p2, G.ax, G.ay) + D_o[o] * sd[p2]) + R_o[o]);
+        sm[e] = mu_o[o] + S.alpha * dm;
+    }
+    __syncthreads();
+    const double tdt = P.tau / dt;
+    double rm[TY / 4], mt[TY / 4];
+    for (int k = 0; k < TY / 4; ++k) {
+        int ly = ly0 + 4 * k, r = r0 + ly, c = c0 + lx;
+        rm[k] = mt[k] = 0.0;
+        if (r < G.ns && c < G.nf) {
+            int p1 = (ly + 1) * W1 + lx + 1, p2 = (ly + 2) * W2 + lx + 2;
+            rm[k] = sp[p2] / dt - 0.5 * lap_at<W1>(sm, p1, G.ax, G.ay) + cmu[pb + (long)r * G.pitch + c];
+            mt[k] = sm[p1];
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < (TY + 2) * W1; e += NTH) {
+        int ly = e / W1, lxx = e - ly * W1;
+        int gr = refl(r0 - 1 + ly, G.ns), gc = refl(c0 - 1 + lxx, G.nf);
+        int p2 = (ly + 1) * W2 + lxx + 1;
+        double ph = sp[p2];
+        sm[e] = tdt * ph - 0.5 * P.kappa * lap_at<W2>(sp, p2, G.ax, G.ay) + P.c1 * reglog(ph) - 0.5 * sm[e] +
+                cphi[pb + (long)gr * G.pitch + gc];
+    }
+    __syncthreads();
+    double acc[4] = {0.0, 0.0, 1e300, -1e300};
+    for (int k = 0; k < TY / 4; ++k) {
+        int ly = ly0 + 4 * k, r = r0 + ly, c = c0 + lx;
+        if (r < G.ns && c < G.nf) {
+            int p1 = (ly + 1) * W1 + lx + 1, p2 = (ly + 2) * W2 + lx + 2;
+            long od = dst * slot_stride + pb + (long)r * G.pitch + c;
+            double ph = sp[p2], rp = sm[p1];
+            double rh = -rm[k] + lap_at<W1>(sm, p1, G.ax, G.ay);
+            double d = jac_diag(ph, tdt, P.c1);
+            phi_s[od] = ph;
+            mu_s[od] = mt[k];
+            Rphi_s[od] = rp;
+            rhs_s[od] = rh;
+            D_s[od] = d;
+            acc[0] += rp * rp + rm[k] * rm[k];
+            acc[1] += rh * rh;
+            acc[2] = fmin(acc[2], d);
+            acc[3] = fmax(acc[3], d);
+        }
+    }
+    const int op[4] = {0, 0, 1, 2};
+    block_reduce_store<4>(acc, op, sred, part + ((long)b * nblk + blk) * NPART);
+}
+
 // ---------------------------------------------------------------------------------
 // Schur-reduced Newton operator  out = A x = x/dt + M (kappa/2 M x + D x),  M = -L   (13-point), the bare
 // operator of vch2d_schur_apply (kernel-level tests); the solver's own application is fused into k_schur_p.
@@ -1348,6 +1435,7 @@ __global__ void k_fin_cg_beta(TrajState *st, const double *__restrict__ part, in
 struct ChebFin {
     int enq, gnblk;
     const double *g0, *gn;                  // [B][gnblk] partials of <z_0,z_0>_Z and of <z_n,z_n>_Z
+    const double *cmin;                     // [B][gnblk] step-ceiling ratios taken by the solve's last row kernel
 };
 __global__ void k_fin_ceiling(TrajState *st, const double *__restrict__ part, int nblk, int strict, int fin_copy, ChebFin cheb) {
     const int b = blockIdx.x;
@@ -1380,7 +1468,13 @@ __global__ void k_fin_ceiling(TrajState *st, const double *__restrict__ part, in
     if (strict && S.lin_active) return;
     double v[NPART];
     const int op[NPART] = {1, 0, 0, 0, 0, 0};
-    fin_reduce(part, nblk, b, v, op, 1);
+    if (cheb.enq >= 0 && cheb.cmin) {
+        double a = 1e300;
+        for (int t = threadIdx.x; t < cheb.gnblk; t += 64) a = fmin(a, cheb.cmin[(long)b * cheb.gnblk + t]);
+        v[0] = wave_min(a);
+    } else {
+        fin_reduce(part, nblk, b, v, op, 1);
+    }
     if (threadIdx.x != 0) return;
     double amax = 2.0;
     if (v[0] < 1e299) amax = fmin(amax, 0.9 * v[0]);

@@ -8,6 +8,7 @@ the build container, imports the reference from /root/reference, copies nothing,
                         rows), default K1 weights: natural march, adjoint sweep on it, cost, and three iterations of
                         the PGD loop G1:353-480 (costs, step lengths, trial counts, final control and state, error
                         metrics through make_golden_r2.errs_1d)
+  g2d_stress_1024.npz   (only with --only stress1024: tens of minutes) the same at BASELINE config 5's own grid, 2 steps
   g2d_stress_256.npz    amp = 1.0 start at 256^2 (the FFT path, twice the size of g2d_stress_128), dt = 1e-3, 3 steps:
                         Newton residual histories and residual-evaluation counts per step (F2:377-423: step ceiling,
                         Armijo, best-trial fallback), sub-sampled fields, per-level norms
@@ -75,9 +76,9 @@ def gen_config1():
          terminal=np.array(trm), u_final_sub=u_k[::2], phi_final_sub=phi_k[::2], nrm_u_final=l2(u_k), nrm_phi_final=l2(phi_k))
 
 
-def gen_stress256():
+def gen_stress(N, M, sub, name):
     F2, K2 = _fresh_import(REF2D, ["Forward2_solver", "config"])
-    N, M, dt = 256, 3, 1e-3
+    dt = 1e-3
     cfg = K2.ForwardSolverConfig(Nx=N, Ny=N, T=M * dt, dt_initial=dt)
     hists, evals = [], []
     orig_newton, orig_res, orig_init = F2.newton_raphson, F2.solve_phi_residual, F2.init_phi_random
@@ -92,7 +93,8 @@ def gen_stress256():
         k["return_residual_history"] = True
         pn, mn, hist = orig_newton(*a, **k)
         hists.append(np.array(hist)); evals.append(count[0])
-        print(f"    256^2 stress step {len(hists)}: {len(hist)} norms, {count[0]} residual evaluations, last {hist[-1]:.3e}", flush=True)
+        print(f"    {N}^2 stress step {len(hists)}: {len(hist)} norms {np.array2string(np.array(hist), precision=3)}, "
+              f"{count[0]} residual evaluations", file=sys.stderr, flush=True)
         return pn, mn
     F2.newton_raphson, F2.solve_phi_residual = recording_newton, counting_res
     F2.init_phi_random = lambda a, b, d, amp=0.1, seed=42, **k: orig_init(a, b, d, amp=1.0, seed=seed)
@@ -105,19 +107,28 @@ def gen_stress256():
     for i, h in enumerate(hists):
         H[i, :len(h)] = h
     l2 = lambda A: np.sqrt((A.reshape(A.shape[0], -1) ** 2).sum(axis=1))
-    save("g2d_stress_256.npz", N=N, M=M, dt=dt, t_hist=t_hist, hists=H, n_hist=np.array([len(h) for h in hists]),
-         res_evals=np.array(evals), phi_sub=phi[:, ::4, ::4], nrm_phi=l2(phi), clipped_frac0=np.mean(np.abs(phi[0]) >= 0.99))
+    save(name, N=N, M=M, dt=dt, t_hist=t_hist, hists=H, n_hist=np.array([len(h) for h in hists]),
+         res_evals=np.array(evals), phi_sub=phi[:, ::sub, ::sub], nrm_phi=l2(phi), clipped_frac0=np.mean(np.abs(phi[0]) >= 0.99))
+
+
+def gen_stress256():
+    gen_stress(256, 3, 4, "g2d_stress_256.npz")
+
+
+def gen_stress1024():
+    """BASELINE config 5's own grid: two steps of the reference at 1024^2 (2.1 M unknowns per SuperLU solve: tens of minutes)."""
+    gen_stress(1024, 2, 16, "g2d_stress_1024.npz")
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", choices=["config1", "stress256"])
+    ap.add_argument("--only", choices=["config1", "stress256", "stress1024"])
     a = ap.parse_args()
     if not os.path.isdir(REF):
         sys.exit("reference checkout not present: golden vectors can only be regenerated in the build container")
     os.chdir(tempfile.mkdtemp(prefix="vch_golden_"))
     import warnings
     warnings.filterwarnings("ignore")
-    for name, fn in (("config1", gen_config1), ("stress256", gen_stress256)):
-        if a.only in (None, name):
+    for name, fn in (("config1", gen_config1), ("stress256", gen_stress256), ("stress1024", gen_stress1024)):
+        if a.only == name or (a.only is None and name != "stress1024"):
             print(name); fn()

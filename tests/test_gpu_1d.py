@@ -210,3 +210,40 @@ def test_bitwise_reproducibility_1d(V):
         runs.append(e.forward(phi0, dts)[0])
         e.close()
     assert np.array_equal(runs[0], runs[1])
+
+
+def test_config1_full_size_vs_reference(V, O1):
+    """BASELINE config 1 at its full size (1D N = 256, T = 1, dt_initial = 5e-3: 200 steps, 202 history rows, default
+    K1 weights) against the reference's own run (tests/golden/make_golden_r3.py): forward march, adjoint sweep, and three
+    iterations of the PGD loop G1:353-480 -- the second of them a line search that returns its last try (5 trials) --
+    through vch1d_forward / _backward / _pgd_* at full size; error metrics against G1:425-450."""
+    g = golden("g1d_config1_256.npz")
+    N, T, dt = int(g["N"]), float(g["T"]), float(g["dt"])
+    t = g["t_hist"]
+    tg, dts = V.time_grid(T, dt)
+    assert len(dts) == 200 and np.array_equal(np.concatenate([[0.0], tg]), t)
+    F1 = V.module("Vch_control_1D.Forward_solver")
+    phi0 = F1.init_phi_random(N, 1e-2, amp=0.01, seed=42, enforce_zero_mean=True)
+    e = V.Engine1D(N=N, max_steps=len(dts))
+    ph, st = e.forward(phi0, dts)
+    assert ph.shape == (202, 257)
+    assert relerr(ph[::2], g["phi_nat_sub"]) < SOLVE, st
+    assert np.allclose(np.sqrt((ph ** 2).sum(axis=1)), g["nrm_phi_nat"], rtol=1e-9)
+    opt = O1.OptParams1D()
+    x = np.linspace(0.0, 1.0, N + 1)
+    phi_T, phi_Q = O1.build_targets(x, t, ph[0].copy(), 1.0, T, 1, 1)
+    assert relerr(phi_T, g["phi_T"]) < 1e-15
+    p, q, r = e.backward(ph, t, opt.b1, opt.b2, phi_Q, phi_T)
+    assert relerr(r[::2], g["r_nat_sub"]) < 1e-8 and relerr(p[::4], g["p_nat_sub"]) < 1e-8
+    assert np.allclose(np.sqrt((q ** 2).sum(axis=1)), g["nrm_q_nat"], rtol=1e-7)
+    e.close()
+    G1 = V.module("Vch_control_1D.GD_1D")
+    K1 = V.module("Vch_control_1D.config")
+    res = G1.run_optimization_resident(K1.ForwardSolverConfig(N=N, T=T, dt_initial=dt), K1.OptimizationConfig(),
+                                       n_iter=int(g["n_iter"]))
+    assert np.allclose(res["costs"], g["costs"], rtol=1e-9), (res["costs"], g["costs"])
+    assert np.allclose(res["alphas"], g["alphas"], rtol=1e-13) and list(res["trials"]) == list(g["trials"])
+    assert max(res["trials"]) == 5
+    assert relerr(res["u"][::2], g["u_final_sub"]) < 1e-7 and relerr(res["phi"][::2], g["phi_final_sub"]) < 1e-7
+    assert np.allclose(res["tracking_error"], g["tracking"], rtol=1e-8)
+    assert np.allclose(res["terminal_error"], g["terminal"], rtol=1e-8)

@@ -414,6 +414,46 @@ def test_one_look_per_step_and_inexact_newton(V, O2):
     assert np.max(np.abs(ph4 - ph)) < 1e-10
 
 
+def test_reduction_free_sweeps_match_cg(V, O2):
+    """Forward solves of a march in the reduction-free (Chebyshev) form -- sweep counts fixed from the spectral bound
+    before the solve, inverse and forward row transform of consecutive sweeps in one kernel (k_cheb_rows), step ceiling in
+    the solve's last row kernel, back substitution inside the trial kernel (k_residual2) -- against the CG form
+    (VCH_CHEB=0): equal Newton / Armijo / solve counts, fields equal to the solves' tolerance, fewer sweeps and fewer
+    launches; the schedule's margin (VCH_CHEB_MARGIN) and the look-per-phase schedule change nothing, bit for bit."""
+    import os
+    N, M = 128, 40
+    t, dts = V.time_grid(M * 1e-3, 1e-3)
+    phi0 = np.stack([O2.init_phi_random(N, N, 1e-2, amp=0.1, seed=42 + i) for i in range(3)])
+    xs = np.linspace(0, 1, N + 1)
+    shape = np.sin(2 * np.pi * xs)[:, None] * np.cos(np.pi * xs)[None, :]
+    u = np.stack([a * np.linspace(0, 1, M + 1)[:, None, None] * shape[None] for a in (3.0, -2.0, 0.5)])
+
+    def march(env):
+        for k, v in env.items():
+            os.environ[k] = v
+        try:
+            e = V.Engine2D(Nx=N, Ny=N, batch=3, max_steps=M)
+            out = e.forward(phi0, dts, u=u)
+            e.close()
+            return out
+        finally:
+            for k in env:
+                del os.environ[k]
+    counts = lambda s: (s["newton_iters"], s["linear_solves"], s["armijo_trials"])
+    ph, st = march({})
+    ph_cg, st_cg = march({"VCH_CHEB": "0"})
+    assert counts(st) == counts(st_cg), (st, st_cg)
+    assert np.max(np.abs(ph - ph_cg)) < 1e-10
+    assert st["linear_iters"] < 0.8 * st_cg["linear_iters"] and st["launches"] < 0.9 * st_cg["launches"], (st, st_cg)
+    assert 0 < st["max_lin_absres"] < 5e-8 * 1.01, st            # every solve inside the forcing rule's absolute target
+    ph0, st0 = march({"VCH_CHEB_MARGIN": "0"})
+    assert np.array_equal(ph, ph0) and counts(st0) == counts(st) and st0["linear_iters"] == st["linear_iters"]
+    ph1, st1 = march({"VCH_NO_SPEC": "1"})
+    assert np.array_equal(ph, ph1) and counts(st1) == counts(st) and st1["linear_iters"] == st["linear_iters"]
+    ph2, st2 = march({"VCH_LIN_ETA": "0"})                       # all solves to round-off (CG form)
+    assert counts(st2) == counts(st) and np.max(np.abs(ph - ph2)) < 1e-10
+
+
 def test_adjoint_sweep_schedule_independent(V, O2):
     """The adjoint sweep's launch schedule (a look every 8 steps once the order of the starting guess has settled, every
     step while it is being raised; sweeps per step from the longest solve since the last look; each solve started from the

@@ -122,3 +122,44 @@ def test_newton_4096_roundoff_floor():
     assert abs(hist[0] / ref[0] - 1) < 1e-9                 # initial residual ~1e12
     assert hist[-1] > 1e-6 and hist[-1] < 1e-2              # stalled above tol, as the reference
     assert relerr(pn[::16], g["phi_new_sub"]) < 1e-6
+
+
+def test_config1_full_size():
+    """BASELINE config 1 at its full size (N = 256, T = 1, dt = 5e-3: 200 steps, 202 history rows, default weights)
+    against the reference's own run (tests/golden/make_golden_r3.py): natural march, adjoint sweep, and three iterations of
+    the PGD loop G1:353-480 including the 'return last try' line search of its second iteration (5 trials)."""
+    g = golden("g1d_config1_256.npz")
+    P = O1.Params1D(N=int(g["N"]), T=float(g["T"]), dt_initial=float(g["dt"]))
+    Op = O1.OptParams1D()
+    phi, x, t = O1.forward(P, solver="banded")
+    assert phi.shape == (202, 257) and np.array_equal(t, g["t_hist"])
+    assert relerr(phi[::2], g["phi_nat_sub"]) < SOLVE
+    assert np.allclose(np.sqrt((phi ** 2).sum(axis=1)), g["nrm_phi_nat"], rtol=1e-9)
+    phi_T, phi_Q = O1.build_targets(x, t, phi[0].copy(), P.Lx, P.T, 1, 1)
+    assert relerr(phi_T, g["phi_T"]) < 1e-15
+    p, q, r = O1.backward(phi, x, t, Op.b1, Op.b2, phi_Q, phi_T, solver="banded")
+    assert relerr(r[::2], g["r_nat_sub"]) < 1e-8 and relerr(p[::4], g["p_nat_sub"]) < 1e-8
+    res = O1.pgd(P, Op, n_iter=int(g["n_iter"]), solver="banded")
+    assert np.allclose(res.costs, g["costs"], rtol=1e-9), (res.costs, g["costs"])
+    assert np.allclose(res.alphas, g["alphas"], rtol=1e-13) and list(res.trials) == list(g["trials"])
+    assert max(res.trials) == 5                                   # the search that returns its last try
+    assert relerr(res.u[::2], g["u_final_sub"]) < 1e-7 and relerr(res.phi[::2], g["phi_final_sub"]) < 1e-7
+    trk, trm = O1.error_metrics(res.phi, phi_Q, phi_T, x, t)
+    assert abs(trk / g["tracking"][-1] - 1) < 1e-8 and abs(trm / g["terminal"][-1] - 1) < 1e-8
+
+
+def test_oracle_1d_error_metrics_plateau_and_stop():
+    """G1:425-450 error metrics, the x2.0 boost after 10 plateau iterations (G1:453-463) and the stop at k = 11
+    (G1:466-473, where the state is NOT advanced), oracle against the reference-made runs."""
+    g = golden("g1d_pgd_32_err.npz")
+    res = O1.pgd(O1.Params1D(N=32, T=0.1, dt_initial=1e-2), O1.OptParams1D(alpha_max=100.0), n_iter=4)
+    assert np.allclose(res.costs, g["costs"], rtol=1e-9)
+    assert np.allclose(res.tracking, g["tracking"], rtol=1e-8) and np.allclose(res.terminal, g["terminal"], rtol=1e-8)
+    g = golden("g1d_pgd_32_stop.npz")
+    res = O1.pgd(O1.Params1D(N=int(g["N"]), T=float(g["T"]), dt_initial=float(g["dt"])),
+                 O1.OptParams1D(kappa_sparsity=float(g["kappa_sparsity"])), n_iter=int(g["n_iter"]))
+    assert res.converged and len(res.alphas) == int(g["stopped_at"]) + 1 == 12
+    assert list(res.trials) == list(g["trials"]) and np.allclose(res.alphas, g["alphas"], rtol=1e-13)
+    assert np.array_equal(np.asarray(res.costs), g["costs"])
+    assert np.allclose(res.tracking, g["tracking"], rtol=1e-10) and np.allclose(res.terminal, g["terminal"], rtol=1e-10)
+    assert not np.any(res.u) and relerr(res.phi, g["phi_final"]) < 1e-9

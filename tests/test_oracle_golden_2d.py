@@ -154,3 +154,44 @@ def test_pgd(tag):
     assert relerr(res.phi, g["phi_final"]) < 1e-8
     if tag == "16_bt":
         assert max(res.attempts) >= 1            # the backtracking branch was exercised
+
+
+# ---------------------------------------------------------------------------------------
+# round-2 goldens: error metrics, plateau boost, stop rule (G2:336-381) -- the ORACLE against the reference-made runs
+# (smoke() and the GPU tests use these oracle functions as their checker)
+# ---------------------------------------------------------------------------------------
+def test_oracle_error_metrics_and_rms_fallback():
+    g = golden("g2d_pgd_16_err.npz")
+    res = O2.pgd(O2.Params2D(Nx=16, Ny=16, T=0.1, dt_initial=1e-2), O2.OptParams(), n_iter=4)
+    assert np.allclose(res.costs, g["costs"], rtol=1e-9)
+    assert np.allclose(res.tracking, g["tracking"], rtol=1e-8) and np.allclose(res.terminal, g["terminal"], rtol=1e-8)
+    # phi_Q = 0: the denominator falls back to sqrt(|Omega| T) (G2:353-354)
+    rz = O2.pgd(O2.Params2D(Nx=16, Ny=16, T=float(g["zq_T"]), dt_initial=float(g["zq_dt"])), O2.OptParams(), n_iter=2,
+                zero_target_q=True)
+    assert np.allclose(rz.costs, g["zq_costs"], rtol=1e-9) and np.allclose(rz.alphas, g["zq_alphas"], rtol=1e-13)
+    assert np.allclose(rz.tracking, g["zq_tracking"], rtol=1e-8) and np.allclose(rz.terminal, g["zq_terminal"], rtol=1e-8)
+
+
+def test_oracle_plateau_boost():
+    """alpha_max = 4e4, 9 iterations: deep backtracking incl. 'return last try' (G2:144-146) and the x1.5 boost after five
+    plateau iterations (G2:365-371), as the reference ran them."""
+    g = golden("g2d_pgd_16_plateau.npz")
+    res = O2.pgd(O2.Params2D(Nx=16, Ny=16, T=float(g["T"]), dt_initial=float(g["dt"])),
+                 O2.OptParams(alpha_max=float(g["alpha_max"])), n_iter=int(g["n_iter"]))
+    assert list(res.attempts) == list(g["attempts"])
+    assert np.allclose(res.alphas, g["alphas"], rtol=1e-12) and np.allclose(res.costs, g["costs"], rtol=1e-8)
+    assert np.allclose(res.tracking, g["tracking"], rtol=1e-7) and np.allclose(res.terminal, g["terminal"], rtol=1e-7)
+    assert relerr(res.u, g["u_final"]) < 1e-7 and relerr(res.phi, g["phi_final"]) < 1e-7
+
+
+def test_oracle_stop_rule():
+    """kappa_sparsity = 10: the zero control is the fixed point, every line search exhausts its 10 attempts, the boost comes
+    every 5 iterations and the loop leaves through `change < 1e-5 and k > 20` at k = 21 (G2:375-381)."""
+    g = golden("g2d_pgd_16_stop.npz")
+    res = O2.pgd(O2.Params2D(Nx=16, Ny=16, T=float(g["T"]), dt_initial=float(g["dt"])),
+                 O2.OptParams(kappa_sparsity=float(g["kappa_sparsity"])), n_iter=int(g["n_iter"]))
+    assert res.converged and len(res.alphas) == int(g["stopped_at"]) + 1 == 22
+    assert list(res.attempts) == list(g["attempts"]) and np.array_equal(np.asarray(res.costs), g["costs"])
+    assert np.allclose(res.alphas, g["alphas"], rtol=1e-13) and np.allclose(res.changes, g["changes"], atol=1e-300)
+    assert np.allclose(res.tracking, g["tracking"], rtol=1e-10) and np.allclose(res.terminal, g["terminal"], rtol=1e-10)
+    assert not np.any(res.u)
