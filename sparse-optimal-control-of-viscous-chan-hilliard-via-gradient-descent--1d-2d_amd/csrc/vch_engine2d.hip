@@ -98,6 +98,12 @@ struct vch2d_ctx {
     // off), chosen for the step being enqueued, sweeps enqueued by the last cheb_solve (-1: the last solve was a CG solve),
     // sweeps per Newton slot of the schedule, and the margin added to what the previous step's plans asked for
     bool cheb_on, cheb_step;
+    // fused evaluation kernels (k_eval: step start and Armijo trial with the starting guess and the `fin` step folded in;
+    // VCH_FUSED=0 restores the separate kernels, results bit-identical) and the per-trajectory arrival counters of their
+    // last-workgroup-done hand-off
+    bool fused_on;
+    int fused_mode;                       // 0 separate kernels, 1 fused with the fin step inside, 2 fused + fin launches
+    unsigned *fin_counter;
     int cheb_enq, spec_chn[4], cheb_margin, cheb_max;
     // starting guess of a step's first Newton solve (k_guess): the first increments of the last GUESS_RING steps (ring,
     // written by k_dmu_ceiling_fin; the adjoint sweep keeps its levels there instead), the guess itself (also that of the
@@ -199,7 +205,8 @@ struct vch2d_ctx {
 // Kernel classes for the in-situ timing of vch2d_prof_begin/_end.
 enum { PC_SCHUR_P = 0, PC_GEMM = 1, PC_RESIDUAL = 2, PC_ADJ_Q = 3, PC_CG_UPDATE = 4, PC_ADJ_RHS = 5, PC_COST = 6,
        PC_PROX = 7, PC_DCT_R0 = 8, PC_DCT_C = 9, PC_DCT_R3 = 10, PC_SCHUR_P1 = 11, PC_CG_ROWS = 12, PC_CG_ROWS1 = 13,
-       PC_NOOP = 14, PC_GUESS = 15, PC_ADJ_GUESS = 16, PC_CHEB_ROWS = 17, PC_CHEB_ROWS0 = 18, PC_NCLS = 19 };
+       PC_NOOP = 14, PC_GUESS = 15, PC_ADJ_GUESS = 16, PC_CHEB_ROWS = 17, PC_CHEB_ROWS0 = 18, PC_RESIDUAL0 = 19,
+       PC_NCLS = 20 };
 
 // an empty kernel: what an event pair measures around it is the cost of the pair itself (vch2d_prof_begin)
 __global__ void k_noop() {}
@@ -384,6 +391,12 @@ extern "C" vch2d_ctx *vch2d_create(const vch2d_params *p, int batch, int max_ste
     c->cheb_on = !(getenv("VCH_CHEB") && atoi(getenv("VCH_CHEB")) == 0);
     c->cheb_step = false;
     c->cheb_enq = -1;
+    // measured on the 512^2 x 1000 x 8 march (profiles/r03_fused_ab.txt): separate kernels 0.564 s, fused with the fin step
+    // by the last-finishing workgroup 0.566 s (the serial tail of that workgroup costs what the saved launch gained), fused
+    // with the fin step as its own launch 0.523 s -- the default
+    c->fused_mode = getenv("VCH_FUSED") ? atoi(getenv("VCH_FUSED")) : 2;
+    c->fused_on = c->fused_mode != 0;
+    c->fin_counter = nullptr;
     for (int &n : c->spec_chn) n = 2;
     c->cheb_margin = 1;
     if (const char *e = getenv("VCH_CHEB_MARGIN")) c->cheb_margin = std::max(0, atoi(e));
@@ -420,6 +433,8 @@ extern "C" vch2d_ctx *vch2d_create(const vch2d_params *p, int batch, int max_ste
     if (hipMalloc((void **)&c->st, sizeof(TrajState) * batch) != hipSuccess) return fail("hipMalloc");
     hipMemsetAsync(c->st, 0, sizeof(TrajState) * batch, c->stream);
     if (hipMalloc((void **)&c->frozen_dev, sizeof(int) * batch) != hipSuccess) return fail("hipMalloc");
+    if (hipMalloc((void **)&c->fin_counter, sizeof(unsigned) * batch) != hipSuccess) return fail("hipMalloc");
+    hipMemsetAsync(c->fin_counter, 0, sizeof(unsigned) * batch, c->stream);
     if (hipHostMalloc((void **)&c->st_host, sizeof(TrajState) * batch) != hipSuccess) return fail("hipHostMalloc");
     // looks through mapped host memory (sync_state); where the platform refuses mapped coherent memory the looks fall back
     // to a copy command and a stream synchronisation
@@ -540,6 +555,7 @@ extern "C" void vch2d_destroy(vch2d_ctx *c) {
         if (q) hipFree(q);
     hipFree(c->st);
     hipFree(c->frozen_dev);
+    if (c->fin_counter) hipFree(c->fin_counter);
     if (c->tw_fh) hipFree(c->tw_fh);
     if (c->tw_sh) hipFree(c->tw_sh);
     if (c->tw_f) hipFree(c->tw_f);
@@ -841,6 +857,17 @@ static int dmu_ceiling(vch2d_ctx *c, int strict) {
 
 #define RESIDUAL_TRIAL()                                                                                                    \
     do {                                                                                                                    \
+        if (cheb && fused) {                                                                                                \
+            GuessArgs gt_ = ga2;                                                                                            \
+            if (!(guess2 && trial_guess_)) gt_.c[0] = 0.0;                                                                  \
+            LAUNCHC(PC_RESIDUAL, (k_eval<2>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s,     \
+                    c->Rphi_s, c->rhs_s, c->D_s, (const double *)c->xf, c->cphi, c->cmu, dt, c->part, (const double *)nullptr, \
+                    (const double *)nullptr, (const double *)nullptr, 0L, (double *)nullptr, gt_, c->x0g, efin_);           \
+            if (!fin_inside)                                                                                                \
+                LAUNCH((k_fin_residual<1>), dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->hist_dev, c->P.kappa, dt,     \
+                       c->lin_tol, eta_, (guess2 && trial_guess_) ? 1 : 0);                                                 \
+            break;                                                                                                          \
+        }                                                                                                                   \
         if (cheb)                                                                                                           \
             LAUNCHC(PC_RESIDUAL, k_residual2, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s,     \
                     c->Rphi_s, c->rhs_s, c->D_s, (const double *)c->xf, c->cphi, c->cmu, dt, c->part);                      \
@@ -868,20 +895,30 @@ static int dmu_ceiling(vch2d_ctx *c, int strict) {
 static int newton_level(vch2d_ctx *c, double dt, const double *un, const double *unp1, long u_stride,
                         const double *wnew_in, bool in_march) {
     const double eta_ = in_march ? c->lin_eta : 0.0;
-    LAUNCH(k_prepare, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s, c->w, un, unp1, u_stride,
-           wnew_in, dt, c->wnew, c->mu0, c->cphi, c->cmu);
-    LAUNCHC(PC_RESIDUAL, (k_residual<0>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s, c->Rphi_s, c->rhs_s,
-           c->D_s, c->mu0, c->x, c->dmu, c->cphi, c->cmu, dt, c->part);
+    const bool fused = in_march && c->fused_on && c->use_fft && !c->half_f && !c->half_s && !wnew_in;
+    // VCH_FUSED=2: fused evaluation kernels, but the `fin` step as its own launch (no hand-off inside the launch)
+    const bool fin_inside = c->fused_mode == 1;
+    const EvalFin efin_{fin_inside ? c->fin_counter : (unsigned *)nullptr, c->hist_dev, c->P.kappa, c->lin_tol, eta_};
     // starting guess of the first solve (marches on the stencil-free path only; forward_core sets the coefficients)
     const bool guess = in_march && c->guess_on && c->guess_c[0] != 0.0;
-    if (guess) {
-        GuessArgs ga;
-        for (int j = 0; j < GUESS_ORD; ++j) {
-            ga.d[j] = c->dprev[(c->guess_step - 1 - j) & (GUESS_RING - 1)];
-            ga.c[j] = c->guess_c[j];
-        }
-        LAUNCHC(PC_GUESS, k_guess, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, ga, (const double *)c->D_s, dt, c->rhs_s, c->x0g,
-               c->part, 0);
+    GuessArgs ga;
+    for (int j = 0; j < GUESS_ORD; ++j) {
+        ga.d[j] = c->dprev[(c->guess_step - 1 - j) & (GUESS_RING - 1)];
+        ga.c[j] = guess ? c->guess_c[j] : 0.0;
+    }
+    if (fused) {
+        // step start in one launch: old-level terms, Newton start value, initial residual, starting guess, `fin` step
+        LAUNCHC(PC_RESIDUAL0, (k_eval<0>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s, c->Rphi_s, c->rhs_s,
+                c->D_s, (const double *)nullptr, c->cphi, c->cmu, dt, c->part, (const double *)c->w, un, unp1, u_stride, c->wnew, ga,
+                c->x0g, efin_);
+    } else {
+        LAUNCH(k_prepare, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s, c->w, un, unp1, u_stride,
+               wnew_in, dt, c->wnew, c->mu0, c->cphi, c->cmu);
+        LAUNCHC(PC_RESIDUAL0, (k_residual<0>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s, c->Rphi_s, c->rhs_s,
+               c->D_s, c->mu0, c->x, c->dmu, c->cphi, c->cmu, dt, c->part);
+        if (guess)
+            LAUNCHC(PC_GUESS, k_guess, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, ga, (const double *)c->D_s, dt, c->rhs_s, c->x0g,
+                   c->part, 0);
     }
     // ... and of the second solve, inside every residual trial (RESIDUAL_TRIAL; k_guess picks the trajectories it applies to)
     const bool guess2 = in_march && c->guess_on && c->guess2_on && c->guess_c2[0] != 0.0;
@@ -890,8 +927,12 @@ static int newton_level(vch2d_ctx *c, double dt, const double *un, const double 
         ga2.d[j] = c->dprev2[(c->guess_step - 1 - j) & (GUESS_RING - 1)];
         ga2.c[j] = guess2 ? c->guess_c2[j] : 0.0;
     }
-    LAUNCH((k_fin_residual<0>), dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->hist_dev, c->P.kappa, dt, c->lin_tol, eta_,
-           guess ? 1 : 0);
+    if (!fused)
+        LAUNCH((k_fin_residual<0>), dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->hist_dev, c->P.kappa, dt, c->lin_tol, eta_,
+               guess ? 1 : 0);
+    else if (!fin_inside)
+        LAUNCH((k_fin_residual<2>), dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->hist_dev, c->P.kappa, dt, c->lin_tol, eta_,
+               guess ? 1 : 0);
     // form of this step's solves: reduction-free where the previous step's plans were short (forward_core decides)
     const bool cheb = in_march && c->cheb_step && c->lin_eta > 0.0;
     if (c->spec) {

@@ -1165,15 +1165,20 @@ __global__ void k_fin_residual(TrajState *st, const double *__restrict__ part, i
     // the record is worked on in registers and written back once: through a reference every field access is a global
     // memory round trip and the state machine below a chain of them (one workgroup, nothing to hide them behind)
     TrajState S = st[b];
+    if (MODE == 2) {               // after k_eval<0> without the fin step inside: the record has not been armed yet
+        if (S.frozen) return;
+        newton_begin(S);
+        S.slot = 1 - S.slot;
+    }
     if (!S.newton_active || !S.need_trial) return;
     double v[NPART];
     const int op[NPART] = {0, 0, 1, 2, 0, 0};
     // guess: k_guess has deflated the right-hand side (MODE 0: of the step's first solve; MODE 1: of its second solve, for
     // a trajectory whose first solve is done); slot 1 holds sum (rhs - A x0)^2, slot 4 sum rhs^2
-    const bool primed = guess && (MODE == 0 || S.iters == 1);
+    const bool primed = guess && (MODE != 1 || S.iters == 1);
     fin_reduce(part, nblk, b, v, op, primed ? 5 : 4);
     if (threadIdx.x != 0) return;
-    fin_residual_update<MODE>(S, v, primed, hist + (long)b * HIST_CAP, kappa, dt, lin_tol, eta);
+    fin_residual_update<(MODE == 1 ? 1 : 0)>(S, v, primed, hist + (long)b * HIST_CAP, kappa, dt, lin_tol, eta);
     st[b] = S;
 }
 
@@ -1250,6 +1255,300 @@ __device__ __forceinline__ void fin_residual_update(TrajState &S, const double (
                 S.newton_active = 0;
             }
         }
+    }
+}
+
+// =================================================================================
+// Fused evaluation kernels of a march on the stencil-free path (one launch where the separate form has three or four):
+//   MODE 0  start of a time step:  k_prepare + k_residual<0> + k_guess(first solve) + k_fin_residual<0>
+//   MODE 2  Armijo trial after a reduction-free solve:  k_residual2 + k_guess(second solve) + k_fin_residual<1>
+// Same arithmetic on the same numbers in the same order as the separate kernels: bit-identical results.
+//
+// The `fin` step (sum the workgroups' partials, Armijo / Newton tests, set-up of the next solve) is done by the workgroup
+// of a trajectory that finishes LAST: every workgroup stores its partials write-through (agent-scope stores), drains them
+// (s_waitcnt vmcnt(0)) and adds 1 to the trajectory's counter (agent-scope atomic, value returned); the one whose add
+// returns nblk - 1 reads all partials with agent-scope loads (never through this CU's L1 or a stale line of its XCD's L2:
+// MI355X_MICROARCH.md, inter-workgroup visibility, 8-byte stores / loads, one lane signalling for its workgroup), sums them
+// in the fixed order of fin_reduce -- whichever workgroup that is, the result has the same bits -- and resets the counter.
+// =================================================================================
+struct EvalFin {
+    unsigned *counter;         // [B], zero between launches
+    double *hist;              // [B][HIST_CAP] residual-norm histories
+    double kappa, lin_tol, eta;
+};
+
+__device__ __forceinline__ void store_agent(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double load_agent(const double *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// fin_reduce on partials handed over inside a launch (agent-scope loads); same order of operations
+__device__ __forceinline__ void fin_reduce_agent(const double *part, int nblk, int b, double (&out)[NPART], const int (&op)[NPART], int n) {
+    double a[NPART];
+#pragma unroll
+    for (int k = 0; k < NPART; ++k) a[k] = op[k] == 0 ? 0.0 : (op[k] == 1 ? 1e300 : -1e300);
+    for (int t = threadIdx.x; t < nblk; t += 64) {
+        const double *p = part + ((long)b * nblk + t) * NPART;
+#pragma unroll
+        for (int k = 0; k < NPART; ++k)
+            if (k < n) {
+                const double v = load_agent(p + k);
+                a[k] = op[k] == 0 ? a[k] + v : (op[k] == 1 ? fmin(a[k], v) : fmax(a[k], v));
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < NPART; ++k)
+        if (k < n) out[k] = op[k] == 0 ? wave_sum(a[k]) : (op[k] == 1 ? wave_min(a[k]) : wave_max(a[k]));
+}
+
+#ifndef EVAL_MINBLK
+#define EVAL_MINBLK 5          // workgroups per CU the register allocation must allow (LDS allows 5)
+#endif
+template <int MODE>
+__global__ __launch_bounds__(NTH, EVAL_MINBLK) void k_eval(Geom G, Phys P, TrajState *st, long slot_stride, double *phi_s, double *mu_s,
+                                              double *Rphi_s, double *rhs_s, double *D_s, const double *dphi, double *cphi,
+                                              double *cmu, double dt, double *part, const double *w, const double *un,
+                                              const double *unp1, long u_stride, double *wnew, GuessArgs ga, double *x0,
+                                              EvalFin fin) {
+    TILE_COORDS;
+    // only the few fields the evaluation needs are read here; the record as a whole is read, advanced and written back by
+    // one thread of the workgroup that finishes last (a per-thread copy of the record would live in private memory)
+    const int S_slot = st[b].slot, S_iters = MODE == 0 ? 0 : st[b].iters;
+    const double S_alpha = MODE == 0 ? 0.0 : st[b].alpha;
+    if (MODE == 0) {
+        if (st[b].frozen) {    // what newton_begin does for a trajectory that sits this march out
+            if (blk == 0 && threadIdx.x == 0) st[b].newton_active = st[b].need_trial = st[b].lin_active = 0;
+            return;
+        }
+    } else {
+        if (!st[b].newton_active || !st[b].need_trial) return;
+    }
+    __shared__ double sp[(TY + 4) * (TX + 4)];
+    __shared__ double sd[MODE == 2 ? (TY + 4) * (TX + 4) : 1];
+    __shared__ double sm[(TY + 2) * (TX + 2)];
+    __shared__ double sr[MODE == 0 ? (TY + 2) * (TX + 2) : 1];
+    __shared__ double sred[NPART * 4];
+    __shared__ int s_last;
+    constexpr int W2 = TX + 4, W1 = TX + 2;
+    const long pb = b * G.plane;
+    // both modes write the evaluated iterate into the OTHER slot: in MODE 0 the new mu (the Newton start value) must not
+    // land where a neighbouring workgroup may still be loading the halo of the old one
+    const int src = S_slot, dst = 1 - S_slot;
+    const double tdt = P.tau / dt;
+    const bool do_guess = ga.c[0] != 0.0 && (MODE == 0 || S_iters == 1);
+    double rm[TY / 4], rh[TY / 4];
+    double acc[5] = {0.0, 0.0, 1e300, -1e300, 0.0};
+    if (MODE == 0) {
+        // ---- k_prepare + k_residual<0> ----
+        load_tile<2>(sp, phi_s + src * slot_stride + pb, G, c0, r0);
+        load_tile<1>(sm, mu_s + src * slot_stride + pb, G, c0, r0);          // mu of the old level
+        __syncthreads();
+        for (int k = 0; k < TY / 4; ++k) {                                   // c_mu needs the Laplacian of the old mu
+            int ly = ly0 + 4 * k, r = r0 + ly, c = c0 + lx;
+            rm[k] = 0.0;
+            if (r < G.ns && c < G.nf) {
+                int p1 = (ly + 1) * W1 + lx + 1, p2 = (ly + 2) * W2 + lx + 2;
+                const double cm = -sp[p2] / dt - 0.5 * lap_at<W1>(sm, p1, G.ax, G.ay);
+                cmu[pb + (long)r * G.pitch + c] = cm;
+                rm[k] = cm;
+            }
+        }
+        __syncthreads();
+        const double gdt = P.gamma / dt;
+        for (int e = threadIdx.x; e < (TY + 2) * W1; e += NTH) {
+            int ly = e / W1, lxx = e - ly * W1;
+            int rr = r0 - 1 + ly, cc = c0 - 1 + lxx;
+            int gr = refl(rr, G.ns), gc = refl(cc, G.nf);
+            int p2 = (ly + 1) * W2 + lxx + 1;
+            long o = (long)gr * G.pitch + gc, ob = pb + o;
+            const double u0 = un ? un[b * u_stride + o] : 0.0, u1 = unp1 ? unp1[b * u_stride + o] : 0.0;
+            const double wo = w[ob];
+            const double wn = ((gdt - 0.5) * wo + 0.5 * (u1 + u0)) / (gdt + 0.5);
+            const double ph = sp[p2], lp = lap_at<W2>(sp, p2, G.ax, G.ay);
+            const double m0 = -P.kappa * lp + (P.c1 * reglog(ph) - 2.0 * P.c2 * ph) - wn;
+            const double cp = -(P.tau / dt) * ph - 0.5 * P.kappa * lp - 2.0 * P.c2 * ph - 0.5 * sm[e] - 0.5 * (wn + wo);
+            sr[e] = tdt * ph - 0.5 * P.kappa * lp + P.c1 * reglog(ph) - 0.5 * m0 + cp;
+            sm[e] = m0;                                                      // mu of the old level is not needed any more
+            if (ly >= 1 && ly <= TY && lxx >= 1 && lxx <= TX && rr < G.ns && cc < G.nf) {   // this workgroup's own nodes
+                wnew[ob] = wn;
+                cphi[ob] = cp;
+            }
+        }
+        __syncthreads();
+        for (int k = 0; k < TY / 4; ++k) {
+            int ly = ly0 + 4 * k, r = r0 + ly, c = c0 + lx;
+            rh[k] = 0.0;
+            if (r < G.ns && c < G.nf) {
+                int p1 = (ly + 1) * W1 + lx + 1, p2 = (ly + 2) * W2 + lx + 2;
+                long od = dst * slot_stride + pb + (long)r * G.pitch + c;
+                const double ph = sp[p2], rp = sr[p1];
+                const double rmv = ph / dt - 0.5 * lap_at<W1>(sm, p1, G.ax, G.ay) + rm[k];
+                const double rhv = -rmv + lap_at<W1>(sr, p1, G.ax, G.ay);
+                const double d = jac_diag(ph, tdt, P.c1);
+                phi_s[od] = ph;
+                mu_s[od] = sm[p1];
+                Rphi_s[od] = rp;
+                D_s[od] = d;
+                rh[k] = rhv;
+                acc[0] += rp * rp + rmv * rmv;
+                acc[2] = fmin(acc[2], d);
+                acc[3] = fmax(acc[3], d);
+            }
+        }
+    } else {
+        // ---- k_residual2 ----
+        const double *phi_o = phi_s + src * slot_stride + pb, *mu_o = mu_s + src * slot_stride + pb;
+        const double *D_o = D_s + src * slot_stride + pb, *R_o = Rphi_s + src * slot_stride + pb;
+        for (int e = threadIdx.x; e < W2 * (TY + 4); e += NTH) {
+            int ly = e / W2, lxx = e - ly * W2;
+            int gr = refl(r0 - 2 + ly, G.ns), gc = refl(c0 - 2 + lxx, G.nf);
+            long o = (long)gr * G.pitch + gc;
+            const double d = dphi[pb + o];
+            sd[e] = d;
+            sp[e] = phi_o[o] + S_alpha * d;
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < (TY + 2) * W1; e += NTH) {
+            int ly = e / W1, lxx = e - ly * W1;
+            int gr = refl(r0 - 1 + ly, G.ns), gc = refl(c0 - 1 + lxx, G.nf);
+            int p2 = (ly + 1) * W2 + lxx + 1;
+            long o = (long)gr * G.pitch + gc;
+            const double dm = 2.0 * ((-0.5 * P.kappa * lap_at<W2>(sd, p2, G.ax, G.ay) + D_o[o] * sd[p2]) + R_o[o]);
+            sm[e] = mu_o[o] + S_alpha * dm;
+        }
+        __syncthreads();
+        double mt[TY / 4];
+        for (int k = 0; k < TY / 4; ++k) {
+            int ly = ly0 + 4 * k, r = r0 + ly, c = c0 + lx;
+            rm[k] = mt[k] = 0.0;
+            if (r < G.ns && c < G.nf) {
+                int p1 = (ly + 1) * W1 + lx + 1, p2 = (ly + 2) * W2 + lx + 2;
+                rm[k] = sp[p2] / dt - 0.5 * lap_at<W1>(sm, p1, G.ax, G.ay) + cmu[pb + (long)r * G.pitch + c];
+                mt[k] = sm[p1];
+            }
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < (TY + 2) * W1; e += NTH) {
+            int ly = e / W1, lxx = e - ly * W1;
+            int gr = refl(r0 - 1 + ly, G.ns), gc = refl(c0 - 1 + lxx, G.nf);
+            int p2 = (ly + 1) * W2 + lxx + 1;
+            double ph = sp[p2];
+            sm[e] = tdt * ph - 0.5 * P.kappa * lap_at<W2>(sp, p2, G.ax, G.ay) + P.c1 * reglog(ph) - 0.5 * sm[e] +
+                    cphi[pb + (long)gr * G.pitch + gc];
+        }
+        __syncthreads();
+        for (int k = 0; k < TY / 4; ++k) {
+            int ly = ly0 + 4 * k, r = r0 + ly, c = c0 + lx;
+            rh[k] = 0.0;
+            if (r < G.ns && c < G.nf) {
+                int p1 = (ly + 1) * W1 + lx + 1, p2 = (ly + 2) * W2 + lx + 2;
+                long od = dst * slot_stride + pb + (long)r * G.pitch + c;
+                double ph = sp[p2], rp = sm[p1];
+                double rhv = -rm[k] + lap_at<W1>(sm, p1, G.ax, G.ay);
+                double d = jac_diag(ph, tdt, P.c1);
+                phi_s[od] = ph;
+                mu_s[od] = mt[k];
+                Rphi_s[od] = rp;
+                D_s[od] = d;
+                rh[k] = rhv;
+                acc[0] += rp * rp + rm[k] * rm[k];
+                acc[2] = fmin(acc[2], d);
+                acc[3] = fmax(acc[3], d);
+            }
+        }
+    }
+    // ---- k_guess: x0 = sum c_j d_j, rhs -= A x0 (A with the D of the iterate just evaluated), sum rhs^2 before / after ----
+    if (do_guess) {
+        double *X = MODE == 0 ? sp : sd;          // x0 with halo 2 (MODE 0: phi is not needed once D has been taken)
+        double *STT = MODE == 0 ? sr : sp;        // kappa/2 M x0 + D x0 with halo 1
+        __syncthreads();                          // everybody is done with sm / sr (and sd)
+        for (int e = threadIdx.x; e < (TY + 2) * W1; e += NTH) {
+            int ly = e / W1, lxx = e - ly * W1;
+            sm[e] = jac_diag(sp[(ly + 1) * W2 + lxx + 1], tdt, P.c1);        // D on the tile + halo 1
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < W2 * (TY + 4); e += NTH) {
+            int ly = e / W2, lxx = e - ly * W2;
+            int gr = refl(r0 - 2 + ly, G.ns), gc = refl(c0 - 2 + lxx, G.nf);
+            long o = pb + (long)gr * G.pitch + gc;
+            double v = ga.c[0] * ga.d[0][o];
+#pragma unroll
+            for (int j = 1; j < GUESS_ORD; ++j)
+                if (ga.c[j] != 0.0) v += ga.c[j] * ga.d[j][o];
+            X[e] = isfinite(v) ? v : 0.0;
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < (TY + 2) * W1; e += NTH) {             // STT is neither X nor sm in either mode
+            int ly = e / W1, lxx = e - ly * W1;
+            int p2 = (ly + 1) * W2 + lxx + 1;
+            STT[e] = -0.5 * P.kappa * lap_at<W2>(X, p2, G.ax, G.ay) + sm[e] * X[p2];
+        }
+        double xv[TY / 4];
+        for (int k = 0; k < TY / 4; ++k) xv[k] = X[(ly0 + 4 * k + 2) * W2 + lx + 2];
+        __syncthreads();
+        const double idt = 1.0 / dt;
+        for (int k = 0; k < TY / 4; ++k) {
+            int ly = ly0 + 4 * k, r = r0 + ly, c = c0 + lx;
+            if (r < G.ns && c < G.nf) {
+                int p1 = (ly + 1) * W1 + lx + 1;
+                const double full = rh[k];
+                const double defl = full - (xv[k] * idt - lap_at<W1>(STT, p1, G.ax, G.ay));
+                x0[pb + (long)r * G.pitch + c] = xv[k];
+                acc[4] += full * full;
+                rh[k] = defl;
+            }
+        }
+    }
+    for (int k = 0; k < TY / 4; ++k) {
+        int r = r0 + ly0 + 4 * k, c = c0 + lx;
+        if (r < G.ns && c < G.nf) {
+            rhs_s[dst * slot_stride + pb + (long)r * G.pitch + c] = rh[k];
+            acc[1] += rh[k] * rh[k];
+        }
+    }
+    // ---- per-workgroup partials, handed to the workgroup that finishes last ----
+    {
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        const int op5[5] = {0, 0, 1, 2, 0};
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            double r_ = op5[k] == 0 ? wave_sum(acc[k]) : (op5[k] == 1 ? wave_min(acc[k]) : wave_max(acc[k]));
+            if (lane == 0) sred[k * 4 + wv] = r_;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double *pp = part + ((long)b * nblk + blk) * NPART;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const double a = sred[k * 4], bb = sred[k * 4 + 1], cc = sred[k * 4 + 2], dd = sred[k * 4 + 3];
+                const double v = op5[k] == 0 ? (a + bb) + (cc + dd)
+                                             : (op5[k] == 1 ? fmin(fmin(a, bb), fmin(cc, dd)) : fmax(fmax(a, bb), fmax(cc, dd)));
+                if (fin.counter) store_agent(pp + k, v);
+                else pp[k] = v;
+            }
+            if (!fin.counter) return;             // a k_fin_residual launch follows
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned old = __hip_atomic_fetch_add(fin.counter + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = old == (unsigned)(nblk - 1) ? 1 : 0;
+        }
+        if (!fin.counter) return;
+        __syncthreads();
+        if (!s_last || threadIdx.x >= 64) return;
+    }
+    // ---- k_fin_residual, by the first wavefront of the last workgroup ----
+    {
+        double v[NPART];
+        const int op[NPART] = {0, 0, 1, 2, 0, 0};
+        fin_reduce_agent(part, nblk, b, v, op, do_guess ? 5 : 4);
+        if (threadIdx.x != 0) return;
+        __hip_atomic_store(fin.counter + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        TrajState S = st[b];
+        if (MODE == 0) {
+            newton_begin(S);
+            S.slot = dst;                         // the evaluated start iterate lives there (a trial flips the slot when accepted)
+        }
+        fin_residual_update<(MODE == 0 ? 0 : 1)>(S, v, do_guess, fin.hist + (long)b * HIST_CAP, fin.kappa, dt, fin.lin_tol, fin.eta);
+        st[b] = S;
     }
 }
 

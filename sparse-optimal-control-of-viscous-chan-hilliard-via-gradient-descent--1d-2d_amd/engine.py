@@ -327,7 +327,7 @@ class Engine2D:
     # -- in-situ kernel timing -------------------------------------------------------------
     PROF_CLASSES = ("schur_p", "dct_gemm", "residual", "adj_q", "cg_update", "adj_rhs", "cost", "prox", "dct_rows_fwd",
                     "dct_cols", "dct_rows_inv", "schur_p_first", "cg_rows_fwd", "cg_rows_fwd_first", "event_pair_noop", "guess",
-                    "adj_guess", "cheb_rows", "cheb_rows_first")
+                    "adj_guess", "cheb_rows", "cheb_rows_first", "residual_first")
 
     def counters(self):
         """(kernel launches, blocking looks of the host at the device state) since the context was created."""

@@ -454,6 +454,45 @@ def test_reduction_free_sweeps_match_cg(V, O2):
     assert counts(st2) == counts(st) and np.max(np.abs(ph - ph2)) < 1e-10
 
 
+def test_fused_evaluation_kernels_bit_identical(V, O2):
+    """k_eval (step start = old-level terms + Newton start value + initial residual + starting guess + `fin` step in one
+    launch; Armijo trial = back substitution + residual + second-solve guess + `fin` step) against the separate kernels
+    (VCH_FUSED=0): the same arithmetic in the same order, so histories and counters are equal bit for bit -- including the
+    sums the last-finishing workgroup of a trajectory takes over the other workgroups' partials (agent-scope hand-off inside
+    the launch).  Run under a control, with a frozen trajectory-free batch of 3 and with uneven work (one trajectory with a
+    much rougher start), twice, to catch a stale partial."""
+    import os
+    N, M = 128, 30
+    t, dts = V.time_grid(M * 1e-3, 1e-3)
+    phi0 = np.stack([O2.init_phi_random(N, N, 1e-2, amp=a, seed=42 + i) for i, a in enumerate((0.1, 0.6, 0.05))])
+    xs = np.linspace(0, 1, N + 1)
+    shape = np.sin(2 * np.pi * xs)[:, None] * np.cos(np.pi * xs)[None, :]
+    u = np.stack([a * np.linspace(0, 1, M + 1)[:, None, None] * shape[None] for a in (3.0, -2.0, 0.5)])
+
+    def march(env):
+        for k, v in env.items():
+            os.environ[k] = v
+        try:
+            e = V.Engine2D(Nx=N, Ny=N, batch=3, max_steps=M)
+            out = [e.forward(phi0, dts, u=u) for _ in range(2)]
+            e.close()
+            return out
+        finally:
+            for k in env:
+                del os.environ[k]
+    key = lambda s: (s["newton_iters"], s["linear_solves"], s["armijo_trials"], s["linear_iters"])
+    (ph, st), (ph_b, st_b) = march({})                      # default: fused kernels, the fin step as its own launch
+    (ph0, st0), _ = march({"VCH_FUSED": "0"})
+    assert np.array_equal(ph, ph_b) and key(st)[:3] == key(st_b)[:3]
+    assert np.array_equal(ph, ph0), float(np.max(np.abs(ph - ph0)))
+    assert key(st) == key(st0), (st, st0)
+    assert st["launches"] < st0["launches"], (st, st0)
+    # ... and with the fin step taken by the workgroup of a trajectory that finishes last (hand-off inside the launch)
+    (ph1, st1), (ph1b, _) = march({"VCH_FUSED": "1"})
+    assert np.array_equal(ph, ph1) and np.array_equal(ph, ph1b) and key(st1) == key(st)
+    assert st1["launches"] < st["launches"], (st1, st)
+
+
 def test_adjoint_sweep_schedule_independent(V, O2):
     """The adjoint sweep's launch schedule (a look every 8 steps once the order of the starting guess has settled, every
     step while it is being raised; sweeps per step from the longest solve since the last look; each solve started from the
