@@ -20,10 +20,11 @@ The one collective of the data path is a single RCCL all-reduce of the cost scal
 `--collective torch` uses torch.distributed on a host copy instead).
 
 One JSON line is printed by rank 0.  Extra objects:
-  roofline      the dominant kernel: algorithmic bytes per launch / mean launch duration, measured with HIP
-                event pairs on the engine's stream(s) during ONE extra PGD iteration in which every context
-                of the rank runs (the same contention as the timed region); `roofline_kernels` lists every
-                profiled kernel the same way, `roofline_newton_stencil` is the north-star kernel
+  roofline      the dominant kernel: algorithmic bytes per launch / mean duration of its LIVE launches, measured with
+                HIP event pairs on the engine's stream(s) during ONE extra PGD iteration in which every context
+                of the rank runs (the same contention as the timed region), the pair's own cost calibrated on an
+                empty kernel and taken off; `roofline_kernels` lists every profiled kernel the same way (with the
+                committed rocprofv3 device-side durations next to it), `roofline_newton_stencil` is the north-star kernel
   cpu_baseline  the CPU oracle (numpy/scipy restatement of the reference, SuperLU solves) timed
                 on this box's host cores on a bounded sample of the same workload (rank 0, N = 1)
 """
@@ -45,51 +46,70 @@ FP64_MFMA_PEAK_TF = 78.6     # = 1/2 of the 157.3 TF FP32 vector/matrix peak of 
 
 # Algorithmic bytes per node per launch (fp64 fields read + written once).
 ALG_BYTES = {
-    "cg_rows_fwd": 72.0,     # z, q, p_old, D, x -> x, z', p', E_rows(Delta p')   (first pass of a CG sweep)
+    "cheb_rows": 56.0,       # row kernel of a reduction-free sweep, j >= 2: E_cols output, b~, y_j, y_{j-1}, D -> y_{j+1}, E_rows(Delta y_{j+1})
+    "cheb_rows_first": 40.0,  # j = 0: E_cols output, D -> b~, y_1, E_rows(Delta y_1)
+    "cg_rows_fwd": 72.0,     # CG form (wide spectra only): z, q, p_old, D, x -> x, z', p', E_rows(Delta p')
     "cg_rows_fwd_first": 40.0,   # z, D -> x (zeroed), p, E_rows(Delta p)
     "schur_p": 72.0,         # GEMM-DCT grids only: z, q, p_old, D, x -> x, z', p, v
     "schur_p_first": 40.0,   # z, D -> x (zeroed), p, v
     "dct_rows_fwd": 16.0,    # field -> field
     "dct_cols": 16.0,        # field -> field (forward transform, multiplier, inverse transform in LDS)
     "dct_rows_inv": 32.0,    # field, D, other -> field (+ the CG dot products)
-    "residual": 88.0,        # trial form: phi, dphi, mu, dmu, c_phi, c_mu -> phi_t, mu_t, R_phi, rhs, D
-    "adj_q": 64.0,           # first pass of an adjoint CG sweep (k_adj_rows_fwd): r, q, ph_old, y -> y, r', ph', E_rows(ph')
-    "cg_update": 24.0, "adj_rhs": 72.0,
-    "guess": 80.0,           # k_guess at order 6: six increments, D, rhs -> rhs, x0
+    "residual": 96.0,        # Armijo trial (k_eval<2>): phi, dphi, mu, D, R_phi, c_phi, c_mu -> phi_t, mu_t, R_phi, rhs, D
+                             # (+ 8 per plane of a folded-in starting guess and 8 for x0: not counted, frac is a lower bound)
+    "residual_first": 104.0,  # start of a step (k_eval<0>): phi, mu, w, u_n, u_n+1 -> w+, c_phi, c_mu, phi, mu0, R_phi, rhs, D
+    "adj_q": 72.0,           # first pass of an adjoint CG sweep (k_adj_rows_fwd): r, q, ph_old, y, D_n -> y, r', ph', E_rows(ph')
+    "cg_update": 24.0, "adj_rhs": 64.0,   # p, q, phi_n, phi_n+1, phiQ_n, phiQ_n+1 -> rhs, D_n
+    "guess": 80.0,           # k_guess at order 6 (CG-form steps only): six increments, D, rhs -> rhs, x0
     "adj_guess": 56.0,       # k_adj_guess at order 4: four levels, p -> ring, x0
 }
-PMC_NAMES = {"cg_rows_fwd": "k_cg_rows_fwd<0, 1024, 10>", "schur_p": "k_schur_p<0>", "dct_rows_fwd": "k_dct_rows<0, 1024, 10>", "dct_cols": "k_dct_cols<1024, 10>",
-             "dct_rows_inv": "k_dct_rows<3, 1024, 10>", "residual": "k_residual<1>", "adj_q": "k_adj_q", "guess": "k_guess",
-             "adj_guess": "k_adj_guess"}
+PMC_NAMES = {"cheb_rows": "k_cheb_rows<1024, 10, 0>", "cheb_rows_first": "k_cheb_rows<1024, 10, 1>", "cg_rows_fwd": "k_cg_rows_fwd<0, 1024, 10>",
+             "schur_p": "k_schur_p<0>", "dct_rows_fwd": "k_dct_rows<0, 1024, 10>", "dct_cols": "k_dct_cols<1024, 10>",
+             "dct_rows_inv": "k_dct_rows<5, 1024, 10>", "residual": "k_eval<2>", "residual_first": "k_eval<0>", "adj_q": "k_adj_rows_fwd<0, 1024, 10>",
+             "guess": "k_guess", "adj_guess": "k_adj_guess", "adj_rhs": "k_adj_rhs"}
 
 
-# kernel classes of the in-bench timing -> kernel names in the committed rocprofv3 summary of the same command
-# (profiles/kernel_stats_contexts{K}.csv = scripts/r2_profile.sh on the final build): device-side durations, for comparison
-ROCPROF_NAMES = {"dct_cols": ("void k_dct_cols<",), "dct_rows_inv": ("void k_dct_rows<3", "void k_dct_rows<4", "void k_dct_rows<5"),
-                 "dct_rows_fwd": ("void k_dct_rows<0",), "cg_rows_fwd": ("void k_cg_rows_fwd<0",),
-                 "cg_rows_fwd_first": ("void k_cg_rows_fwd<1",), "residual": ("void k_residual<",),
-                 "adj_q": ("void k_adj_rows_fwd<",), "guess": ("k_guess(",), "adj_guess": ("k_adj_guess(",),
-                 "adj_rhs": ("k_adj_rhs(",), "cg_update": ("k_cg_finish(",), "cost": ("k_cost(",), "prox": ("k_grad_prox(",)}
+# kernel classes of the in-bench timing -> kernel names in the committed rocprofv3 summaries of the same command
+# (profiles/live_stats_contexts{K}.txt = scripts/r3_profile.sh on the final build, device-side durations over LIVE launches;
+# profiles/live_stats_march_b8.txt = scripts/r3_prof_march.sh, one context of 8 trajectories alone on the chip)
+ROCPROF_NAMES = {"dct_cols": ("k_dct_cols<",), "dct_rows_inv": ("k_dct_rows<3", "k_dct_rows<4", "k_dct_rows<5"),
+                 "dct_rows_fwd": ("k_dct_rows<0",), "cg_rows_fwd": ("k_cg_rows_fwd<0",), "cg_rows_fwd_first": ("k_cg_rows_fwd<1",),
+                 "cheb_rows": ("k_cheb_rows<1024, 10, 0>",), "cheb_rows_first": ("k_cheb_rows<1024, 10, 1>",),
+                 "residual": ("k_eval<2>", "k_residual2", "k_residual<1>"), "residual_first": ("k_eval<0>", "k_residual<0>"),
+                 "adj_q": ("k_adj_rows_fwd<",), "guess": ("k_guess",), "adj_guess": ("k_adj_guess",),
+                 "adj_rhs": ("k_adj_rhs",), "cg_update": ("k_cg_finish",), "cost": ("k_cost",), "prox": ("k_grad_prox",)}
 
 
-def rocprof_reference(contexts):
-    """{class: mean device-side duration in us} from the committed rocprofv3 --kernel-trace --stats summary, or {}."""
-    import csv
-    path = os.path.join(ROOT, "profiles", f"kernel_stats_contexts{contexts}.csv")
+def live_stats_table(name):
+    """{kernel name: (live calls, live mean us)} from a committed scripts/r3_live_stats.py table, or {}."""
+    path = os.path.join(ROOT, "profiles", name)
     out = {}
     try:
-        rows = list(csv.DictReader(open(path)))
+        with open(path) as fh:
+            for ln in fh:
+                if ln.startswith("#") or ln.startswith("kernel"):
+                    continue
+                f = ln.split()
+                if len(f) < 7:
+                    continue
+                out[" ".join(f[:-6])] = (float(f[-5]), float(f[-3]))
     except OSError:
-        return out, None
+        return {}, None
+    return out, os.path.relpath(path, ROOT)
+
+
+def rocprof_reference(table):
+    """{class: mean device-side duration in us over live launches} from a live_stats_table, call-weighted over the class's kernels."""
+    out = {}
     for cls, prefixes in ROCPROF_NAMES.items():
         calls = tot = 0.0
-        for r in rows:
-            if any(r["Name"].startswith(p) for p in prefixes):
-                calls += float(r["Calls"])
-                tot += float(r["TotalDurationNs"])
+        for name, (n, mean) in table.items():
+            if any(name.startswith(p) for p in prefixes):
+                calls += n
+                tot += n * mean
         if calls:
-            out[cls] = tot / calls * 1e-3
-    return out, os.path.relpath(path, ROOT)
+            out[cls] = tot / calls
+    return out
 
 
 def parse():
@@ -388,7 +408,9 @@ def run(a, world, rank, local, dist):
         on_all(lambda k, e: e.prof_begin(400000))
         on_all(lambda k, e: e.pgd_iterate(1))
         profs = on_all(lambda k, e: e.prof_end())
+        spans_c = on_all(lambda k, e: e.prof_spans())
         prof = {k: dict(ms=sum(p[k]["ms"] for p in profs), launches=sum(p[k]["launches"] for p in profs)) for k in profs[0]}
+        spans = {k: np.concatenate([sp[k] for sp in spans_c]) for k in spans_c[0]}
         nodes = (N + 1) * (N + 1) * Bc
         alg = {k: ("hbm", v * nodes) for k, v in ALG_BYTES.items()}
         alg["dct_gemm"] = ("mfma", 2.0 * (N + 1) ** 3 * Bc)
@@ -405,51 +427,67 @@ def run(a, world, rank, local, dist):
                 pj = json.load(fh)
             pk, pb = pj["kernels"], float(pj.get("trajectories_per_launch", 8))
             for k, name in PMC_NAMES.items():
-                if name in pk:
+                if name in pk and pk[name].get("fetch_corrected") is not None:
                     pmc[k] = (pk[name]["fetch_corrected"] + pk[name]["write_raw"]) * Bc / pb
             pmc_src = f"profiles/pmc_traffic.json (committed rocprofv3 --pmc pass at {pb:g} trajectories per launch, scaled x{Bc / pb:g})"
         except (OSError, KeyError, ValueError):
             pmc = {}
         use_pmc = (N == 512 and engs[0].uses_fft)
 
-        # what an event pair spans around an EMPTY kernel (256 pairs per context, recorded by prof_begin while the other
-        # context runs): dispatch latency + queueing behind the other context's kernels.  Reported, NOT subtracted:
-        # avg_us below is the plain event-pair span, so `frac` is a lower bound of what the kernel itself achieves
-        # (rocprofv3's device-side durations of the same kernels are attached as rocprof_avg_us, see rocprof_reference).
-        noop = prof.get("event_pair_noop", dict(ms=0.0, launches=0))
-        extra["event_pair_span_of_empty_kernel_us"] = noop["ms"] * 1e3 / max(noop["launches"], 1)
+        # What an event pair spans around an EMPTY kernel (256 pairs per context, recorded by prof_begin while the other
+        # context runs): the pair's own cost -- two barrier packets, dispatch latency, queueing behind the other context.
+        # A launch whose trajectories are all gated off lasts no longer than that: launches within 2.5 us of it are counted as
+        # no-ops and left out of the LIVE mean.  The kernel's own time is estimated as live span - (empty span - 1 us, the
+        # empty kernel itself); `frac` uses that estimate, `frac_span` the plain span (a lower bound).
+        noop_sp = spans.get("event_pair_noop", np.zeros(0))
+        noop_us = float(np.median(noop_sp)) if len(noop_sp) else 0.0
+        extra["event_pair_span_of_empty_kernel_us"] = noop_us
+        pair_cost = max(noop_us - 1.0, 0.0)
 
-        # device-side durations of the same kernels from the committed rocprofv3 summary of this command at the same
-        # number of contexts (not measured in this run; for the reader to set against the event-pair spans)
-        rp, rp_src = rocprof_reference(K) if use_pmc else ({}, None)
+        # device-side durations of the same kernels over live launches from the committed rocprofv3 traces: the same command
+        # at the same number of contexts, and one context of 8 trajectories alone on the chip (a march + an adjoint sweep)
+        tab_c, src_c = live_stats_table(f"live_stats_contexts{K}.txt") if use_pmc else ({}, None)
+        tab_a, src_a = live_stats_table("live_stats_march_b8.txt") if use_pmc else ({}, None)
+        rp, rp_alone = rocprof_reference(tab_c), rocprof_reference(tab_a)
 
         def roof_of(k):
             kind, per = alg[k]
-            avg_s = prof[k]["ms"] * 1e-3 / max(prof[k]["launches"], 1)
+            sp = spans.get(k, np.zeros(0))
+            live = sp[sp > noop_us + 2.5] if len(sp) else sp
+            span_us = float(live.mean()) if len(live) else prof[k]["ms"] * 1e3 / max(prof[k]["launches"], 1)
+            avg_s = max(span_us - pair_cost, 0.5) * 1e-6
+            share = prof[k]["ms"] / max(sum(tot.values()), 1e-30)
             if kind == "hbm":
                 ach = per / avg_s / 1e9
                 d = dict(kernel=k, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
                          frac=ach / HBM_PEAK_GBS, traffic=(pmc.get(k) if use_pmc else None),
                          traffic_source=(pmc_src if (use_pmc and k in pmc) else None), avg_us=avg_s * 1e6,
-                         launches=prof[k]["launches"], algorithmic_bytes_per_launch=per,
-                         share_of_profiled_kernel_time=prof[k]["ms"] / max(sum(tot.values()), 1e-30))
+                         live_span_us=span_us, frac_span=per / (span_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                         launches=prof[k]["launches"], live_launches=int(len(live)),
+                         noop_share=(1.0 - len(live) / len(sp)) if len(sp) else None,
+                         algorithmic_bytes_per_launch=per, share_of_profiled_kernel_time=share)
                 if k in rp:
                     d["rocprof_avg_us"] = rp[k]
                     d["rocprof_frac"] = per / (rp[k] * 1e-6) / 1e9 / HBM_PEAK_GBS
-                    d["rocprof_source"] = rp_src
+                    d["rocprof_source"] = src_c
+                if k in rp_alone:      # 8 trajectories per launch, nothing else on the chip
+                    per8 = per / Bc * 8
+                    d["alone_b8_avg_us"] = rp_alone[k]
+                    d["alone_b8_frac"] = per8 / (rp_alone[k] * 1e-6) / 1e9 / HBM_PEAK_GBS
+                    d["alone_b8_source"] = src_a
                 return d
             ach = per / avg_s / 1e12
             return dict(kernel=k, bound="mfma", achieved=ach, peak=FP64_MFMA_PEAK_TF, unit="TFLOP/s",
                         frac=ach / FP64_MFMA_PEAK_TF, traffic=None, traffic_source=None, avg_us=avg_s * 1e6,
                         launches=prof[k]["launches"], algorithmic_flops_per_launch=per,
-                        share_of_profiled_kernel_time=prof[k]["ms"] / max(sum(tot.values()), 1e-30))
+                        share_of_profiled_kernel_time=share)
         ranked = sorted((k for k in tot if k in alg), key=lambda k: -tot[k])
         roof = roof_of(ranked[0]) if ranked else None
         extra["roofline_kernels"] = [roof_of(k) for k in ranked]
         # the Newton stencil kernel of the path: the residual / Schur right-hand side evaluation (the CG sweeps of
         # power-of-two grids apply the operator in the DCT basis and contain no stencil; GEMM-DCT grids use k_schur_p)
         for k in ("schur_p", "residual"):
-            if k in tot:
+            if k in tot and k in alg:
                 extra["roofline_newton_stencil"] = roof_of(k)
                 break
         extra["dct_path"] = ("in-LDS Stockham FFT of the even extension, plan 8x8x4x4 at 512^2 (8x8x8 / 8x8x8x4 at 256^2 / 1024^2)"

@@ -244,10 +244,18 @@ int vch2d_free_energy(vch2d_ctx *ctx, const double *phi_hist, int rows, const do
  *   10 DCT row pass (inverse, with the CG dot products)  11 first sweep of a solve (k_schur_p<1>)
  *   12 first pass of a CG sweep (k_cg_rows_fwd: CG vector updates + Delta p + forward row DCT)  13 the same, first sweep
  *   14 an empty kernel launched 256 times by _begin: the cost of an event pair itself
- *   15 starting guess of a step's first Newton solve (k_guess)  16 starting guess of an adjoint solve (k_adj_guess) */
-#define VCH_PROF_CLASSES 17
+ *   15 starting guess of a step's first Newton solve (k_guess)  16 starting guess of an adjoint solve (k_adj_guess)
+ *   17 row kernel of a reduction-free sweep (k_cheb_rows: inverse row DCT + Chebyshev update + forward row DCT)
+ *   18 the same, first kernel of a solve (b~ = P^-1 rhs, y_1)
+ *   19 start of a time step (k_eval<0>: old-level terms + initial residual + starting guess; or k_residual<0>)
+ *   (class 2 is the Armijo trial: k_eval<2> / k_residual2 / k_residual<1>)
+ * _spans (after _end) returns every recorded launch: its class and the elapsed milliseconds of its event pair, in launch
+ * order, at most cap entries; the return value is the number recorded.  With these the caller separates launches whose
+ * trajectories were all gated off (they last as long as the empty kernel of class 14) from live ones. */
+#define VCH_PROF_CLASSES 20
 int vch2d_prof_begin(vch2d_ctx *ctx, int max_launches);
 int vch2d_prof_end(vch2d_ctx *ctx, double *ms_out, int64_t *count_out, int ncls);
+int vch2d_prof_spans(vch2d_ctx *ctx, int32_t *cls_out, float *ms_out, int cap);
 
 /* ------------------------------------------------------------------ 1D ---- */
 

@@ -155,6 +155,7 @@ SIGNATURES = {
     "vch_comm_allreduce_cost": (C.c_int, [_P, C.POINTER(C.c_void_p), C.c_int, C.c_long, _D]),
     "vch2d_prof_begin": (C.c_int, [_P, C.c_int]),
     "vch2d_prof_end": (C.c_int, [_P, _D, C.POINTER(C.c_int64), C.c_int]),
+    "vch2d_prof_spans": (C.c_int, [_P, _I32, C.POINTER(C.c_float), C.c_int]),
 }
 
 _lib = None

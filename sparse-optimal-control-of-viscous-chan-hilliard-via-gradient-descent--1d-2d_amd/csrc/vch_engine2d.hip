@@ -805,8 +805,12 @@ static int cheb_solve(vch2d_ctx *c, double dt, int n_enq) {
 #define CHEB_ROWS(C_, LG_)                                                                                             \
     do {                                                                                                               \
         const int rpw = 2 * (C_ >> c->fax.logL);                                                                       \
-        LAUNCHC((j == 0 ? PC_CHEB_ROWS0 : PC_CHEB_ROWS), (k_cheb_rows<C_, LG_>), dim3((ns + rpw - 1) / rpw, 1, c->B),  \
-                dim3(FftThreads<C_, LG_>::T), G, c->fax, a, (const double *)c->t2, c->t1, (const TrajState *)c->st);   \
+        if (j == 0)                                                                                                    \
+            LAUNCHC(PC_CHEB_ROWS0, (k_cheb_rows<C_, LG_, 1>), dim3((ns + rpw - 1) / rpw, 1, c->B),                     \
+                    dim3(FftThreads<C_, LG_>::T), G, c->fax, a, (const double *)c->t2, c->t1, (const TrajState *)c->st); \
+        else                                                                                                           \
+            LAUNCHC(PC_CHEB_ROWS, (k_cheb_rows<C_, LG_, 0>), dim3((ns + rpw - 1) / rpw, 1, c->B),                      \
+                    dim3(FftThreads<C_, LG_>::T), G, c->fax, a, (const double *)c->t2, c->t1, (const TrajState *)c->st); \
     } while (0)
         if (c->fax.logL == 10) CHEB_ROWS(1024, 10);
         else if (c->fax.logL == 9) CHEB_ROWS(1024, 9);
@@ -2139,6 +2143,20 @@ extern "C" int vch2d_prof_end(vch2d_ctx *c, double *ms_out, int64_t *count_out, 
         HIPCHK(hipEventElapsedTime(&ms, c->prof_ev[2 * i], c->prof_ev[2 * i + 1]));
         int k = c->prof_cls[i];
         if (k < ncls) { ms_out[k] += ms; count_out[k]++; }
+    }
+    return (int)c->prof_cls.size();
+}
+
+extern "C" int vch2d_prof_spans(vch2d_ctx *c, int32_t *cls_out, float *ms_out, int cap) {
+    CTXCHK(c);
+    ARGCHK(cls_out && ms_out && cap >= 0, "NULL output");
+    if (c->prof_on) return vch_fail(VCH_ERR_STATE, "vch2d_prof_spans: call vch2d_prof_end first");
+    const int n = (int)std::min<size_t>(c->prof_cls.size(), (size_t)cap);
+    for (int i = 0; i < n; ++i) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, c->prof_ev[2 * i], c->prof_ev[2 * i + 1]));
+        cls_out[i] = c->prof_cls[i];
+        ms_out[i] = ms;
     }
     return (int)c->prof_cls.size();
 }

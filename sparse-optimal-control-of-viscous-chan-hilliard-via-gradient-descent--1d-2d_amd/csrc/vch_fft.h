@@ -901,10 +901,13 @@ struct ChebSweepArgs {
     double *keep1, *keep2;                // ring planes of this step (or NULL)
 };
 
-template <int C, int LOGL>
-__global__ __launch_bounds__((FftThreads<C, LOGL>::T)) void k_cheb_rows(Geom G, FftAxis ax, ChebSweepArgs a, const double *__restrict__ in,
+// FIRST = 1: the kernel with j = 0 (a separate instantiation: its branches fold, and profiles tell the two apart)
+template <int C, int LOGL, int FIRST>
+__global__ __launch_bounds__((FftThreads<C, LOGL>::T)) void k_cheb_rows(Geom G, FftAxis ax, ChebSweepArgs a_, const double *__restrict__ in,
                                                                        double *__restrict__ out, const TrajState *__restrict__ st) {
     const int b = blockIdx.z;
+    ChebSweepArgs a = a_;
+    if (FIRST) a.j = 0;
     if (!st[b].lin_active || a.j > st[b].cheb_n) return;
     const bool last = a.j == st[b].cheb_n;
     __shared__ double2 buf[FftLds<C>::SIZE];

@@ -345,6 +345,16 @@ class Engine2D:
         check(self.lib.vch2d_prof_end(self.ctx, _dp(ms), cnt.ctypes.data_as(C.POINTER(C.c_int64)), n))
         return {k: dict(ms=float(ms[i]), launches=int(cnt[i])) for i, k in enumerate(self.PROF_CLASSES)}
 
+    def prof_spans(self):
+        """{class: float32 array of the event-pair spans (us) of every launch recorded between prof_begin and prof_end}."""
+        cap = 1 << 20
+        cls = np.zeros(cap, dtype=np.int32)
+        ms = np.zeros(cap, dtype=np.float32)
+        n = check(self.lib.vch2d_prof_spans(self.ctx, cls.ctypes.data_as(C.POINTER(C.c_int32)),
+                                            ms.ctypes.data_as(C.POINTER(C.c_float)), cap))
+        n = min(int(n), cap)
+        return {k: 1e3 * ms[:n][cls[:n] == i] for i, k in enumerate(self.PROF_CLASSES)}
+
 
 class Engine1D:
     """One GPU context for `batch` 1D trajectories on N+1 nodes (N <= 4096)."""
