@@ -73,6 +73,9 @@ typedef struct vch_stats {
                                   5 % of the Newton tolerance */
     int64_t host_syncs;        /* blocking looks of the host at the device state during the call */
     int64_t launches;          /* kernel launches of the call */
+    /* ABI version 3 (a caller must check vch_abi_version() >= 3 before passing a vch_stats: the library writes all fields) */
+    int64_t unconverged_solves; /* adjoint solves that the speculative schedule's sweeps did not finish (each ended below
+                                  10 x the solve tolerance, or the whole sweep was repeated with the rigorous budget) */
 } vch_stats;
 
 typedef struct vch2d_ctx vch2d_ctx;

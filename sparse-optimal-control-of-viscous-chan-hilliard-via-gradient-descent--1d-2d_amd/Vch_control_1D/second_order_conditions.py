@@ -75,12 +75,37 @@ def approximate_second_order_condition(fwd_config: ForwardSolverConfig, u_star, 
     with quiet():
         cost_star = calculate_cost(phi_star, u_star, phi_Q_target, phi_T_target, x, t_hist, b1, b2, b3, kappa, verbose=False)
     grad_star = r_star + b3 * u_star
-    out: List[float] = []
-    for _ in range(num_directions):
-        h = _generate_direction(u_star, r_star, u_min, u_max, kappa, b3, rng)
-        u_p = u_star + epsilon * h
-        phi_p, _, _ = run_main_simulation(fwd_config=fwd_config, store_history=True, control_input=u_p, verbose=False)
-        with quiet():
-            cost_p = calculate_cost(phi_p, u_p, phi_Q_target, phi_T_target, x, t_hist, b1, b2, b3, kappa, verbose=False)
-        out.append((cost_p - cost_star - epsilon * np.sum(grad_star * h)) / (0.5 * epsilon ** 2))
-    return out
+    # all directions first (the same draws in the same order as the reference's loop, S1:137-150), then their perturbed
+    # controls marched as one batch of trajectories with one batched cost evaluation
+    dirs = [_generate_direction(u_star, r_star, u_min, u_max, kappa, b3, rng) for _ in range(num_directions)]
+    costs = _perturbed_costs([u_star + epsilon * h for h in dirs], fwd_config, phi_Q_target, phi_T_target, x, t_hist,
+                             b1, b2, b3, kappa)
+    return [(cost_p - cost_star - epsilon * np.sum(grad_star * h)) / (0.5 * epsilon ** 2) for h, cost_p in zip(dirs, costs)]
+
+
+MAX_BATCH = 64
+
+
+def _perturbed_costs(controls, fwd_config, phi_Q_target, phi_T_target, x, t_hist, b1, b2, b3, kappa):
+    """J(u) for every control of the list: `run_main_simulation(fwd_config, control_input=u)` (default start:
+    init_phi_random(amp=0.01, seed=42), F1:316) and `calculate_cost`, batched over the controls."""
+    from ..engine import time_grid, make_opt
+    from ._ctx import engine_for_config
+    from .Forward_solver import init_phi_random, delta_sep
+    cfg = fwd_config if fwd_config is not None else ForwardSolverConfig()
+    N = int(cfg.N)
+    _, dts = time_grid(float(cfg.T), float(cfg.dt_initial))
+    phi0 = init_phi_random(N, delta_sep, amp=0.01, seed=42, enforce_zero_mean=True)
+    opt = make_opt(b1=b1, b2=b2, b3=b3, kappa_sparsity=kappa)
+    costs = []
+    for k0 in range(0, len(controls), MAX_BATCH):
+        chunk = controls[k0:k0 + MAX_BATCH]
+        nb = len(chunk)
+        U = np.stack(chunk)
+        eng = engine_for_config(cfg, batch=nb, max_steps=max(len(dts), 1))
+        phi_p, _ = eng.forward(np.broadcast_to(phi0, (nb, N + 1)), dts, u=U, store=True)
+        phi_p = phi_p.reshape((nb,) + phi_p.shape[-2:])
+        tile = lambda a: np.broadcast_to(a, (nb,) + np.shape(a))
+        J = eng.cost(phi_p, U, tile(phi_Q_target), tile(phi_T_target), x, t_hist, opt)
+        costs.extend(float(v) for v in np.atleast_2d(J)[:, 4])
+    return costs

@@ -59,18 +59,47 @@ def approximate_second_order_condition_2d(u_star, r_star, phi_star, x, y, t_hist
     with quiet():
         cost_star = calculate_cost(phi_star, u_star, phi_Q_target, phi_T_target, x, y, t_hist, opt)
     grad_star = r_star + opt.b3 * u_star
-    out: List[float] = []
     print(f"Testing {num_directions} random directions in the critical cone...")
-    for i in range(num_directions):
-        h = _generate_direction(u_star, r_star, u_min, u_max, rng)
-        u_p = u_star + epsilon * h
-        phi_p, _, _ = run_main_simulation(config=fwd_config, store_history=True, control_input=u_p, verbose=False)
-        with quiet():
-            cost_p = calculate_cost(phi_p, u_p, phi_Q_target, phi_T_target, x, y, t_hist, opt)
+    # all directions are drawn first -- the same draws in the same order as the reference's loop (S2:178-186), so seeded
+    # results are unchanged -- and the perturbed controls are then marched as ONE batch of trajectories (MAX_BATCH at a
+    # time) with one batched cost evaluation, instead of num_directions marches of batch 1
+    dirs = [_generate_direction(u_star, r_star, u_min, u_max, rng) for _ in range(num_directions)]
+    costs = _perturbed_costs([u_star + epsilon * h for h in dirs], fwd_config, phi_Q_target, phi_T_target, x, y, t_hist, opt)
+    out: List[float] = []
+    for i, (h, cost_p) in enumerate(zip(dirs, costs)):
         d2 = (cost_p - cost_star - epsilon * np.sum(grad_star * h)) / (0.5 * epsilon ** 2)
         out.append(float(d2))
         print(f"  Direction {i+1}/{num_directions}: estimated d²J/dh² ≈ {d2:.6e}")
     return out
+
+
+MAX_BATCH = 8      # perturbed controls marched side by side (each needs its own state and control history on the device)
+
+
+def _perturbed_costs(controls, fwd_config, phi_Q_target, phi_T_target, x, y, t_hist, opt):
+    """J(u) for every control of the list: the marches of `run_main_simulation(config, control_input=u)` (default start:
+    init_phi_random(amp=0.1, seed=42), F2:517) and `calculate_cost`, batched over the controls."""
+    from ..engine import time_grid
+    from ._ctx import engine_for_config
+    from .Forward2_solver import init_phi_random, DELTA_SEP
+    cfg = fwd_config
+    Nx, Ny = int(cfg.Nx), int(cfg.Ny)
+    _, dts = time_grid(float(cfg.T), float(cfg.dt_initial))
+    phi0 = init_phi_random(Nx, Ny, DELTA_SEP, amp=0.1, seed=42)
+    costs = []
+    for k0 in range(0, len(controls), MAX_BATCH):
+        chunk = controls[k0:k0 + MAX_BATCH]
+        nb = len(chunk)
+        U = np.stack(chunk)
+        rows = U.shape[1]
+        eng = engine_for_config(cfg, batch=nb, max_steps=max(len(dts), rows - 1, 1))
+        Um = U[:, :len(dts) + 1] if rows > len(dts) + 1 else U            # rows beyond the march are never read (F2:545-548)
+        phi_p, _ = eng.forward(np.broadcast_to(phi0, (nb,) + phi0.shape), dts, u=np.ascontiguousarray(Um), store=True)
+        phi_p = phi_p.reshape((nb,) + phi_p.shape[-3:])
+        tile = lambda a: np.broadcast_to(a, (nb,) + np.shape(a))
+        J = eng.cost(phi_p, U, tile(phi_Q_target), tile(phi_T_target), t_hist, opt, x, y)
+        costs.extend(float(v) for v in np.atleast_2d(J)[:, 4])
+    return costs
 
 
 def sparsity_statistics(u_optimal, r_optimal, kappa: float, tol: float = 1e-6):

@@ -89,7 +89,8 @@ class OptParams(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("newton_iters", C.c_int64), ("linear_solves", C.c_int64), ("linear_iters", C.c_int64),
                 ("armijo_trials", C.c_int64), ("max_lin_relres", C.c_double), ("seconds", C.c_double),
-                ("max_lin_absres", C.c_double), ("host_syncs", C.c_int64), ("launches", C.c_int64)]
+                ("max_lin_absres", C.c_double), ("host_syncs", C.c_int64), ("launches", C.c_int64),
+                ("unconverged_solves", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -14,7 +14,7 @@
 thread_local char g_vch_err[512] = "";
 
 extern "C" const char *vch_last_error(void) { return g_vch_err; }
-extern "C" int vch_abi_version(void) { return 2; }
+extern "C" int vch_abi_version(void) { return 3; }
 extern "C" int vch_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return -1;
@@ -97,7 +97,11 @@ struct vch2d_ctx {
     // reduction-free (Chebyshev) form of the forward solves of a march (cheb_solve): allowed at all (VCH_CHEB=0 turns it
     // off), chosen for the step being enqueued, sweeps enqueued by the last cheb_solve (-1: the last solve was a CG solve),
     // sweeps per Newton slot of the schedule, and the margin added to what the previous step's plans asked for
-    bool cheb_on, cheb_step;
+    bool cheb_on;
+    int spec_form[4];                     // per Newton slot: bit 0 = enqueue the reduction-free sequence, bit 1 = the CG sequence
+    bool debug_guess;                     // VCH_DEBUG_GUESS, read once at creation
+    bool adj_guess_off, adj_safe;         // VCH_ADJ_GUESS_OFF, VCH_ADJ_SAFE (diagnostics), read at the start of every sweep
+    long redo_iters;                      // sweeps of an adjoint pass that had to be repeated (0 otherwise)
     // fused evaluation kernels (k_eval: step start and Armijo trial with the starting guess and the `fin` step folded in;
     // VCH_FUSED=0 restores the separate kernels, results bit-identical) and the per-trajectory arrival counters of their
     // last-workgroup-done hand-off
@@ -111,17 +115,19 @@ struct vch2d_ctx {
     // increment goes to
     double *dprev[GUESS_RING], *x0g;
     bool guess_on;
-    double guess_c[GUESS_ORD];            // coefficients of d_{n-1} .. d_{n-GUESS_ORD} (all 0: no guess this step)
     int guess_wr, guess_step;             // ring slot of this step's increment (-1: not kept); step index within the march
-    int guess_used, guess_max;            // increments this step's guess extrapolates over; largest order allowed
-    GuessPolicy guess_pol;
-    // the same for the step's SECOND Newton solve (its own ring; usable while every marching trajectory takes a second solve
-    // step after step: run2 = length of that run)
+    int guess_max;                        // largest order allowed
+    // per trajectory (a trajectory's orders follow from its own history, whatever its batch mates do): order policies of the
+    // first / second solve, orders used in the step being enqueued, length of the run of steps with a second solve
+    std::vector<GuessPolicy> pol1, pol2;
+    std::vector<int> used1, used2, run2;
+    GuessPolicy pol1_all, pol2_all;       // batches beyond GUESS_BMAX trajectories: one policy fed with the worst trajectory
+    int run2_all;
+    GuessArgs gtab1, gtab2;               // coefficient tables of the step being enqueued (all 0 = no guess)
+    unsigned gmask1, gmask2;              // bit b: trajectory b has a guess for its first / second solve this step
+    // the same for the step's SECOND Newton solve (its own ring)
     double *dprev2[GUESS_RING];
-    double guess_c2[GUESS_ORD];
-    int guess_used2, guess_run2;
     bool guess2_on;
-    GuessPolicy guess_pol2;
     double *gpart2;                       // second half of gpart
     double *gpart3;                       // [2][B][gnblk + ns] partials of <z',z'>_Z of the stencil-free sweep
     double *gpart;                        // [B][gnblk] partials written by the GEMM epilogue
@@ -389,7 +395,10 @@ extern "C" vch2d_ctx *vch2d_create(const vch2d_params *p, int batch, int max_ste
     c->spec_slots = 2;
     for (int &n : c->spec_cgb) n = 12;
     c->cheb_on = !(getenv("VCH_CHEB") && atoi(getenv("VCH_CHEB")) == 0);
-    c->cheb_step = false;
+    for (int &f : c->spec_form) f = 3;
+    c->debug_guess = getenv("VCH_DEBUG_GUESS") != nullptr;
+    c->adj_guess_off = c->adj_safe = false;
+    c->redo_iters = 0;
     c->cheb_enq = -1;
     // measured on the 512^2 x 1000 x 8 march (profiles/r03_fused_ab.txt): separate kernels 0.564 s, fused with the fin step
     // by the last-finishing workgroup 0.566 s (the serial tail of that workgroup costs what the saved launch gained), fused
@@ -527,15 +536,18 @@ extern "C" vch2d_ctx *vch2d_create(const vch2d_params *p, int batch, int max_ste
     }
     // starting guess of a step's first Newton solve (k_guess): stencil-free sweep only; VCH_GUESS=0 turns it off
     c->guess_on = c->use_fft && !c->half_f && !c->half_s && !(getenv("VCH_GUESS") && atoi(getenv("VCH_GUESS")) == 0);
-    for (double &g : c->guess_c) g = 0.0;
-    for (double &g : c->guess_c2) g = 0.0;
-    c->guess_used2 = c->guess_run2 = 0;
-    c->guess_pol2.reset();
+    memset(&c->gtab1, 0, sizeof(c->gtab1));
+    memset(&c->gtab2, 0, sizeof(c->gtab2));
+    c->gmask1 = c->gmask2 = 0;
+    c->pol1.resize(batch);
+    c->pol2.resize(batch);
+    c->used1.assign(batch, 0);
+    c->used2.assign(batch, 0);
+    c->run2.assign(batch, 0);
+    c->run2_all = 0;
     c->guess2_on = !(getenv("VCH_GUESS2") && atoi(getenv("VCH_GUESS2")) == 0);
     c->guess_wr = -1;
     c->guess_step = 0;
-    c->guess_used = 0;
-    c->guess_pol.reset();
     c->guess_max = 6;          // beyond, the weights (sum |c_j| = 2^order - 1) amplify what the inexact solves left in the increments
     if (const char *e = getenv("VCH_GUESS_MAX")) c->guess_max = std::max(1, std::min(GUESS_ORD, atoi(e)));
     if (hipStreamSynchronize(c->stream) != hipSuccess) return fail("hipStreamSynchronize");
@@ -710,11 +722,10 @@ constexpr int CG_CHUNK = 24;      // iterations enqueued between two looks at th
 // solving -- converged, frozen, or waiting for an Armijo trial -- keep their x.
 static int schur_solve(vch2d_ctx *c, double dt, int budget, bool look) {
     c->cg_last = -1;
-    c->cheb_enq = -1;
     if (budget <= 0) return 0;
     const double c0 = 1.0 / dt, c2 = 0.5 * c->P.kappa;
     double *zb[2] = {c->r, c->cg_z2};               // z_k lives in zb[k & 1]
-    VCHCHK(precond(c, c->rhs_s, c->slot_stride, zb[0], 3, nullptr, c0, 0.0, 1.0, c2, 1));      // z = P^-1 rhs, <z,z>_Z
+    VCHCHK(precond(c, c->rhs_s, c->slot_stride, zb[0], 3, nullptr, c0, 0.0, 1.0, c2, 5));      // z = P^-1 rhs, <z,z>_Z (CG-form trajectories)
     const bool spectral = c->use_fft && !c->half_f && !c->half_s;      // stencil-free sweep (k_cg_rows_fwd)
     if (!spectral) LAUNCH(k_fin_cg_init, dim3(c->B), dim3(64), c->st, c->gpart, c->gnblk);     // else: inside the first sweep
     int done = 0;
@@ -779,7 +790,6 @@ static int schur_solve(vch2d_ctx *c, double dt, int budget, bool look) {
 // the number its own plan asks for (TrajState::cheb_n, set with the solve's tolerance by k_fin_residual) and stores its
 // finished increment x0 + y in c->x; one whose plan is longer than n_enq is left unfinished (k_fin_ceiling).
 static int cheb_solve(vch2d_ctx *c, double dt, int n_enq) {
-    c->cg_last = -1;
     c->cheb_enq = n_enq;
     const Geom &G = c->G;
     const int ns = G.ns, nf = G.nf;
@@ -787,7 +797,7 @@ static int cheb_solve(vch2d_ctx *c, double dt, int n_enq) {
     const double scale = 1.0 / (4.0 * (double)c->fax.N * (double)c->sax.N);
     {   // E_rows(rhs), then E_cols, 1 / P(m), E_cols (the transform pair's scale is applied by k_cheb_rows)
         SpecArgs sp{c0, 0.0, 1.0, c2, c->ms, c->mf, nullptr, c->D_s, c->slot_stride, c->gpart, c->gpart2, 0};
-        const int gate = 1;
+        const int gate = 8;
         DCT_ROWS_ANY(0, (const double *)c->rhs_s, c->slot_stride, c->t1);
         const double scale = 1.0;
         if (c->sax.logL == 10) DCT_COLS_10();
@@ -836,11 +846,12 @@ static int dmu_ceiling(vch2d_ctx *c, int strict) {
     const bool spectral = c->use_fft && !c->half_f && !c->half_s;
     const ChebFin nocheb{-1, 0, nullptr, nullptr, nullptr};
     if (spectral && c->cheb_enq >= 0) {
-        // the solve's last row kernel has stored dphi (c->xf), kept it for the guesses and taken the ceiling ratios; the
-        // trial kernel (k_residual2) does the back substitution itself
+        // reduction-free solves: the last row kernel has stored dphi (c->xf), kept it for the guesses and taken the ceiling
+        // ratios; the trial kernel does the back substitution itself
         LAUNCH(k_fin_ceiling, dim3(c->B), dim3(64), c->st, c->part, c->nblk, strict, -1,
                ChebFin{c->cheb_enq, c->gnblk, c->gpart, c->gpart2, c->gpart3});
-    } else if (spectral && c->cg_last >= 0) {
+    }
+    if (spectral && c->cg_last >= 0) {
         const int last = c->cg_last, rd = last & 1;
         FinSolveArgs f{c->gpart, c->gpart2, c->gpart3 + (size_t)rd * c->B * c->gnblk, c->gnblk, last >= 1 ? 1 : 0, rd, c->lin_maxit,
                        c->cg_p[last & 1], -1};
@@ -849,7 +860,7 @@ static int dmu_ceiling(vch2d_ctx *c, int strict) {
                c->guess_wr >= 0 ? c->dprev[c->guess_wr] : (double *)nullptr,
                (c->guess_wr >= 0 && c->guess2_on) ? c->dprev2[c->guess_wr] : (double *)nullptr);
         LAUNCH(k_fin_ceiling, dim3(c->B), dim3(64), c->st, c->part, c->nblk, strict, rd ^ 1, nocheb);
-    } else {
+    } else if (!spectral) {
         LAUNCH(k_dmu_ceiling, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->x, c->phi_s, c->D_s, c->Rphi_s, c->dmu, c->xf,
                c->part);
         LAUNCH(k_fin_ceiling, dim3(c->B), dim3(64), c->st, c->part, c->nblk, strict, -1, nocheb);
@@ -859,30 +870,33 @@ static int dmu_ceiling(vch2d_ctx *c, int strict) {
     return 0;
 }
 
+// One residual evaluation of the pending Armijo trials.  inline_dmu (marches on the stencil-free path): the back
+// substitution happens inside the trial kernel, whichever form the solve took (k_eval<2>, or k_residual2 with VCH_FUSED=0).
 #define RESIDUAL_TRIAL()                                                                                                    \
     do {                                                                                                                    \
-        if (cheb && fused) {                                                                                                \
-            GuessArgs gt_ = ga2;                                                                                            \
-            if (!(guess2 && trial_guess_)) gt_.c[0] = 0.0;                                                                  \
+        const bool tg_ = guess2 && trial_guess_;                                                                            \
+        if (inline_dmu && fused) {                                                                                          \
+            GuessArgs gt_ = c->gtab2;                                                                                       \
+            if (!tg_) memset(gt_.c, 0, sizeof(gt_.c));                                                                      \
             LAUNCHC(PC_RESIDUAL, (k_eval<2>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s,     \
                     c->Rphi_s, c->rhs_s, c->D_s, (const double *)c->xf, c->cphi, c->cmu, dt, c->part, (const double *)nullptr, \
                     (const double *)nullptr, (const double *)nullptr, 0L, (double *)nullptr, gt_, c->x0g, efin_);           \
             if (!fin_inside)                                                                                                \
                 LAUNCH((k_fin_residual<1>), dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->hist_dev, c->P.kappa, dt,     \
-                       c->lin_tol, eta_, (guess2 && trial_guess_) ? 1 : 0);                                                 \
+                       c->lin_tol, eta_, tg_ ? (int)c->gmask2 : 0, cheb_max_);                                              \
             break;                                                                                                          \
         }                                                                                                                   \
-        if (cheb)                                                                                                           \
+        if (inline_dmu)                                                                                                     \
             LAUNCHC(PC_RESIDUAL, k_residual2, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s,     \
                     c->Rphi_s, c->rhs_s, c->D_s, (const double *)c->xf, c->cphi, c->cmu, dt, c->part);                      \
         else                                                                                                                \
             LAUNCHC(PC_RESIDUAL, (k_residual<1>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s, \
                     c->Rphi_s, c->rhs_s, c->D_s, c->mu0, c->xf, c->dmu, c->cphi, c->cmu, dt, c->part);                      \
-        if (guess2 && trial_guess_)                                                                                         \
-            LAUNCHC(PC_GUESS, k_guess, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, ga2, (const double *)c->D_s,  \
-                    dt, c->rhs_s, c->x0g, c->part, 1);                                                                      \
+        if (tg_)                                                                                                            \
+            LAUNCHC(PC_GUESS, k_guess, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->gtab2,                     \
+                    (const double *)c->D_s, dt, c->rhs_s, c->x0g, c->part, 1);                                              \
         LAUNCH((k_fin_residual<1>), dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->hist_dev, c->P.kappa, dt, c->lin_tol, \
-               eta_, (guess2 && trial_guess_) ? 1 : 0);                                                                    \
+               eta_, tg_ ? (int)c->gmask2 : 0, cheb_max_);                                                                  \
     } while (0)
 
 // One implicit time level for the whole batch (F2:323-427).  On entry the old level is
@@ -899,50 +913,46 @@ static int dmu_ceiling(vch2d_ctx *c, int strict) {
 static int newton_level(vch2d_ctx *c, double dt, const double *un, const double *unp1, long u_stride,
                         const double *wnew_in, bool in_march) {
     const double eta_ = in_march ? c->lin_eta : 0.0;
-    const bool fused = in_march && c->fused_on && c->use_fft && !c->half_f && !c->half_s && !wnew_in;
+    const bool spectral = c->use_fft && !c->half_f && !c->half_s;
+    const bool fused = in_march && c->fused_on && spectral && !wnew_in;
+    const bool inline_dmu = in_march && spectral;
+    // the form of every solve is decided on the device, per trajectory (k_fin_residual: plans of at most cheb_max sweeps take
+    // the reduction-free form); -1 = the CG form always (bare Newton calls, solves to round-off, GEMM-DCT grids)
+    const int cheb_max_ = (in_march && spectral && c->cheb_on && eta_ > 0.0) ? c->cheb_max : -1;
     // VCH_FUSED=2: fused evaluation kernels, but the `fin` step as its own launch (no hand-off inside the launch)
     const bool fin_inside = c->fused_mode == 1;
-    const EvalFin efin_{fin_inside ? c->fin_counter : (unsigned *)nullptr, c->hist_dev, c->P.kappa, c->lin_tol, eta_};
-    // starting guess of the first solve (marches on the stencil-free path only; forward_core sets the coefficients)
-    const bool guess = in_march && c->guess_on && c->guess_c[0] != 0.0;
-    GuessArgs ga;
-    for (int j = 0; j < GUESS_ORD; ++j) {
-        ga.d[j] = c->dprev[(c->guess_step - 1 - j) & (GUESS_RING - 1)];
-        ga.c[j] = guess ? c->guess_c[j] : 0.0;
-    }
+    const EvalFin efin_{fin_inside ? c->fin_counter : (unsigned *)nullptr, c->hist_dev, c->P.kappa, c->lin_tol, eta_, cheb_max_};
+    // starting guesses (marches on the stencil-free path only; forward_core fills the coefficient tables): of the first
+    // solve here, of the second solve inside the residual trial of slot 0
+    const bool guess = in_march && c->guess_on && c->gmask1 != 0;
+    const bool guess2 = in_march && c->guess_on && c->guess2_on && c->gmask2 != 0;
     if (fused) {
-        // step start in one launch: old-level terms, Newton start value, initial residual, starting guess, `fin` step
+        // step start in one launch: old-level terms, Newton start value, initial residual, starting guess (, `fin` step)
+        GuessArgs g1_ = c->gtab1;
+        if (!guess) memset(g1_.c, 0, sizeof(g1_.c));
         LAUNCHC(PC_RESIDUAL0, (k_eval<0>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s, c->Rphi_s, c->rhs_s,
-                c->D_s, (const double *)nullptr, c->cphi, c->cmu, dt, c->part, (const double *)c->w, un, unp1, u_stride, c->wnew, ga,
+                c->D_s, (const double *)nullptr, c->cphi, c->cmu, dt, c->part, (const double *)c->w, un, unp1, u_stride, c->wnew, g1_,
                 c->x0g, efin_);
+        if (!fin_inside)
+            LAUNCH((k_fin_residual<2>), dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->hist_dev, c->P.kappa, dt, c->lin_tol, eta_,
+                   guess ? (int)c->gmask1 : 0, cheb_max_);
     } else {
         LAUNCH(k_prepare, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s, c->w, un, unp1, u_stride,
                wnew_in, dt, c->wnew, c->mu0, c->cphi, c->cmu);
         LAUNCHC(PC_RESIDUAL0, (k_residual<0>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s, c->Rphi_s, c->rhs_s,
                c->D_s, c->mu0, c->x, c->dmu, c->cphi, c->cmu, dt, c->part);
         if (guess)
-            LAUNCHC(PC_GUESS, k_guess, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, ga, (const double *)c->D_s, dt, c->rhs_s, c->x0g,
-                   c->part, 0);
-    }
-    // ... and of the second solve, inside every residual trial (RESIDUAL_TRIAL; k_guess picks the trajectories it applies to)
-    const bool guess2 = in_march && c->guess_on && c->guess2_on && c->guess_c2[0] != 0.0;
-    GuessArgs ga2;
-    for (int j = 0; j < GUESS_ORD; ++j) {
-        ga2.d[j] = c->dprev2[(c->guess_step - 1 - j) & (GUESS_RING - 1)];
-        ga2.c[j] = guess2 ? c->guess_c2[j] : 0.0;
-    }
-    if (!fused)
+            LAUNCHC(PC_GUESS, k_guess, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->gtab1, (const double *)c->D_s, dt, c->rhs_s,
+                   c->x0g, c->part, 0);
         LAUNCH((k_fin_residual<0>), dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->hist_dev, c->P.kappa, dt, c->lin_tol, eta_,
-               guess ? 1 : 0);
-    else if (!fin_inside)
-        LAUNCH((k_fin_residual<2>), dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->hist_dev, c->P.kappa, dt, c->lin_tol, eta_,
-               guess ? 1 : 0);
-    // form of this step's solves: reduction-free where the previous step's plans were short (forward_core decides)
-    const bool cheb = in_march && c->cheb_step && c->lin_eta > 0.0;
+               guess ? (int)c->gmask1 : 0, cheb_max_);
+    }
     if (c->spec) {
         for (int s = 0; s < c->spec_slots; ++s) {
-            if (cheb) VCHCHK(cheb_solve(c, dt, c->spec_chn[s]));
-            else VCHCHK(schur_solve(c, dt, c->spec_cgb[s], false));
+            // the launch sequences of the forms the trajectories took in this slot of the previous step (both where they
+            // differed; a trajectory whose form has no sequence here is finished by the loop below)
+            if (cheb_max_ >= 0 && (c->spec_form[s] & 1)) VCHCHK(cheb_solve(c, dt, c->spec_chn[s]));
+            if (cheb_max_ < 0 || (c->spec_form[s] & 2)) VCHCHK(schur_solve(c, dt, c->spec_cgb[s], false));
             VCHCHK(dmu_ceiling(c, 1));
             // the trial of slot 0 is the one a second solve normally follows; a trajectory whose second solve comes later
             // (a rejected trial, a first solve that did not fit its slot) starts it from zero
@@ -961,25 +971,27 @@ static int newton_level(vch2d_ctx *c, double dt, const double *un, const double 
             if (c->st_host[b].newton_active && c->st_host[b].need_trial) return true;
         return false;
     };
-    if (getenv("VCH_DEBUG_GUESS")) {
+    if (c->debug_guess) {
         const TrajState &S = c->st_host[0];
         fprintf(stderr, "guess order %d / %d (run %d) | traj 0: ratio %.3e / %.3e solves %d sweeps %d %d %d normR %.3e active %d "
-                "tol %.3e %.3e %.3e kT %.6f %.6f %.6f\n",
-                c->guess_used, c->guess_used2, c->guess_run2, S.guess_ratio, S.guess_ratio2, S.step_solves, S.step_lin[0],
+                "tol %.3e %.3e %.3e kT %.6f %.6f %.6f form %d %d %d\n",
+                c->used1[0], c->used2[0], c->run2[0], S.guess_ratio, S.guess_ratio2, S.step_solves, S.step_lin[0],
                 S.step_lin[1], S.step_lin[2], S.normR, S.newton_active, S.step_tol[0], S.step_tol[1], S.step_tol[2],
-                S.step_kT[0], S.step_kT[1], S.step_kT[2]);
+                S.step_kT[0], S.step_kT[1], S.step_kT[2], S.step_form[0], S.step_form[1], S.step_form[2]);
     }
     int guard = 0;
     while (any_active()) {
         if (++guard > NEWTON_MAXIT + 2) return vch_fail(VCH_ERR_STATE, "newton_level: state machine did not terminate");
-        if (cheb) {        // the plans of the pending solves are in the state the host has just read
-            int need = 0;
-            for (int b = 0; b < c->B; ++b)
-                if (c->st_host[b].newton_active && c->st_host[b].lin_active) need = std::max(need, c->st_host[b].cheb_n);
-            VCHCHK(cheb_solve(c, dt, need));
-        } else {
-            VCHCHK(schur_solve(c, dt, cg_budget(c, true), true));
+        // the pending solves' forms and plans are in the state the host has just read
+        int need = -1, budget = 0;
+        for (int b = 0; b < c->B; ++b) {
+            const TrajState &S = c->st_host[b];
+            if (!S.newton_active || !S.lin_active) continue;
+            if (S.use_cheb) need = std::max(need, S.cheb_n);
+            else budget = std::max(budget, S.lin_budget);
         }
+        if (need >= 0) VCHCHK(cheb_solve(c, dt, need));
+        if (budget > 0) VCHCHK(schur_solve(c, dt, std::min(budget, c->lin_maxit), true));
         VCHCHK(dmu_ceiling(c, 0));
         int tguard = 0;
         const bool trial_guess_ = true;
@@ -989,41 +1001,39 @@ static int newton_level(vch2d_ctx *c, double dt, const double *un, const double 
             if (++tguard > ARMIJO_TRIALS + 2) return vch_fail(VCH_ERR_STATE, "newton_level: Armijo loop did not terminate");
         } while (any_trial());
     }
-    if (c->spec) {
-        // next step's schedule: as many slots as the busiest trajectory had linear solves (+ failed trials do not count:
-        // they are rare and the loop above absorbs them), and sweeps for the longest solve + 1, within the rigorous bound
-        int solves = 1, sweeps[4] = {1, 1, 1, 1}, longest = 1, bound = 1;
+    {
+        // next step's schedule: as many slots as the busiest trajectory had linear solves (failed trials do not count: they
+        // are rare and the loop above absorbs them); per slot the launch sequences of the forms seen there, CG sweeps for the
+        // longest CG solve + 1 within the rigorous bound, Chebyshev sweeps for the longest plan + the margin
+        int solves = 1, sweeps[4] = {1, 1, 1, 1}, chn[4] = {0, 0, 0, 0}, form[4] = {0, 0, 0, 0}, longest = 1, bound = 1, chmax = 0,
+            form_any = 0;
         for (int b = 0; b < c->B; ++b) {
             const TrajState &S = c->st_host[b];
             if (S.frozen) continue;
             solves = std::max(solves, S.step_solves);
-            for (int s = 0; s < 4; ++s) sweeps[s] = std::max(sweeps[s], S.step_lin[s]);
-            longest = std::max(longest, S.step_lin_max);
             bound = std::max(bound, S.lin_budget);
-        }
-        c->spec_slots = std::min(solves, 4);
-        if (!cheb)
-            for (int s = 0; s < 4; ++s) {
-                // a slot this step did not use is sized like the longest solve seen
-                const int want = (s < solves ? sweeps[s] : longest) + 1;
-                c->spec_cgb[s] = std::max(2, std::min(std::min(want, bound), 64));
+            for (int s = 0; s < 4 && s < S.step_solves; ++s) {
+                if (S.step_form[s]) {
+                    chn[s] = std::max(chn[s], S.step_chn[s]);
+                    chmax = std::max(chmax, S.step_chn[s]);
+                    form[s] |= 1;
+                } else {
+                    sweeps[s] = std::max(sweeps[s], S.step_lin[s]);
+                    longest = std::max(longest, S.step_lin[s]);
+                    form[s] |= 2;
+                }
+                form_any |= form[s];
             }
-    }
-    {
-        int solves = 1;
-        for (int b = 0; b < c->B; ++b)
-            if (!c->st_host[b].frozen) solves = std::max(solves, c->st_host[b].step_solves);
-        // the Chebyshev plans of this step's solves (known whichever form ran): the next step's solves are enqueued with
-        // what these asked for + the margin, and take the reduction-free form while no plan is longer than cheb_max
-        int chn[4] = {0, 0, 0, 0}, chmax = 0;
-        for (int b = 0; b < c->B; ++b) {
-            const TrajState &S = c->st_host[b];
-            if (S.frozen) continue;
-            for (int s = 0; s < 4 && s < S.step_solves; ++s) chn[s] = std::max(chn[s], S.step_chn[s]);
         }
-        for (int s = 0; s < 4 && s < solves; ++s) chmax = std::max(chmax, chn[s]);
-        for (int s = 0; s < 4; ++s) c->spec_chn[s] = (s < solves ? chn[s] : chmax) + c->cheb_margin;
-        c->cheb_step = c->cheb_on && c->use_fft && !c->half_f && !c->half_s && chmax <= c->cheb_max;
+        if (!form_any) form_any = cheb_max_ >= 0 ? 1 : 2;
+        c->spec_slots = std::min(solves, 4);
+        for (int s = 0; s < 4; ++s) {
+            const bool seen = s < solves && form[s] != 0;
+            c->spec_form[s] = seen ? form[s] : form_any;                    // a slot this step did not use: any form seen
+            const int want = ((seen && (form[s] & 2)) ? sweeps[s] : longest) + 1;
+            c->spec_cgb[s] = std::max(2, std::min(std::min(want, bound), 64));
+            c->spec_chn[s] = ((seen && (form[s] & 1)) ? chn[s] : chmax) + c->cheb_margin;
+        }
     }
     return 0;
 }
@@ -1039,7 +1049,10 @@ static void fill_stats(vch2d_ctx *c, vch_stats *s, float ms) {
         s->armijo_trials += S.ntrials;
         s->max_lin_relres = std::max(s->max_lin_relres, S.lin_maxrel);
         s->max_lin_absres = std::max(s->max_lin_absres, S.lin_maxabs);
+        s->unconverged_solves += S.lin_unconv;
     }
+    s->linear_iters += c->redo_iters;          // a repeated adjoint sweep: its first pass counts too
+    s->host_syncs += 0;
     s->host_syncs = c->n_sync;
     s->launches = c->n_launch;
     s->seconds = ms * 1e-3;
@@ -1360,24 +1373,35 @@ static int forward_core(vch2d_ctx *c, const double *u_dev, int u_rows, const dou
     LAUNCH(k_mass, c->grid, dim3(NTH), c->G, c->st, c->slot_stride, c->phi_s, c->wts_mass, 0, c->part);
     LAUNCH(k_fin_mass, dim3(c->B), dim3(64), c->st, c->part, c->nblk, 1);
     if (hist_out) LAUNCH(k_copy_plane, c->grid, dim3(NTH), c->G, c->phi_s, c->G.plane, hist_out, hs);
-    c->guess_pol.reset();
-    c->guess_pol2.reset();
-    c->guess_run2 = 0;
-    c->cheb_step = false;             // the first step of a march has no plans to go by: CG form
+    const bool per_traj = c->B <= GUESS_BMAX;
+    for (auto &q : c->pol1) q.reset();
+    for (auto &q : c->pol2) q.reset();
+    std::fill(c->run2.begin(), c->run2.end(), 0);
+    c->pol1_all.reset();
+    c->pol2_all.reset();
+    c->run2_all = 0;
+    for (int &f : c->spec_form) f = 3;      // the first step of a march has nothing to go by: both launch sequences
     for (int step = 0; step < M; ++step) {
         const double *un = nullptr, *unp1 = nullptr;
         if (u_dev && step < u_rows - 1) {        // F2:545-548
             un = u_dev + (long)step * c->G.plane;
             unp1 = u_dev + (long)(step + 1) * c->G.plane;
         }
-        // guess for the step's first Newton solve (k_guess): the increment rate d_k / dt_k, taken at the step midpoints, is
+        // guess for the step's first Newton solve: the increment rate d_k / dt_k, taken at the step midpoints, is
         // extrapolated to this step's midpoint by the polynomial through the last `order` steps; this step's increment
-        // replaces the oldest one in the ring
-        for (double &g : c->guess_c) g = 0.0;
+        // replaces the oldest one in the ring.  The order is every trajectory's own (its policy sees its own ratios only).
+        memset(c->gtab1.c, 0, sizeof(c->gtab1.c));
+        memset(c->gtab2.c, 0, sizeof(c->gtab2.c));
+        c->gtab1.per_traj = c->gtab2.per_traj = per_traj ? 1 : 0;
+        c->gmask1 = c->gmask2 = 0;
         c->guess_wr = -1;
         c->guess_step = step;
         if (c->guess_on) {
             c->guess_wr = step & (GUESS_RING - 1);
+            for (int j = 0; j < GUESS_ORD; ++j) {
+                c->gtab1.d[j] = c->dprev[(step - 1 - j) & (GUESS_RING - 1)];
+                c->gtab2.d[j] = c->dprev2[(step - 1 - j) & (GUESS_RING - 1)];
+            }
             // returns the order actually used: on ragged time grids the weights of a high order can grow large, and a guess
             // of large magnitude costs accuracy when the solve cancels it again (x = x0 + y); the weights of order 6 on a
             // uniform grid sum to 63 in magnitude, anything above is answered with a lower order
@@ -1403,8 +1427,21 @@ static int forward_core(vch2d_ctx *c, const double *u_dev, int u_rows, const dou
                 for (int j = 0; j < GUESS_ORD; ++j) cf[j] = 0.0;
                 return 0;
             };
-            c->guess_used = weights(c->guess_pol.choose(step, c->guess_max), c->guess_c);
-            c->guess_used2 = weights(c->guess2_on ? c->guess_pol2.choose(std::min(step, c->guess_run2), c->guess_max) : 0, c->guess_c2);
+            if (per_traj) {
+                for (int b = 0; b < c->B; ++b) {
+                    c->used1[b] = weights(c->pol1[b].choose(step, c->guess_max), c->gtab1.c[b]);
+                    c->used2[b] = weights(c->guess2_on ? c->pol2[b].choose(std::min(step, c->run2[b]), c->guess_max) : 0, c->gtab2.c[b]);
+                    if (c->used1[b] >= 1) c->gmask1 |= 1u << b;
+                    if (c->used2[b] >= 1) c->gmask2 |= 1u << b;
+                }
+            } else {
+                const int u1 = weights(c->pol1_all.choose(step, c->guess_max), c->gtab1.c[0]);
+                const int u2 = weights(c->guess2_on ? c->pol2_all.choose(std::min(step, c->run2_all), c->guess_max) : 0, c->gtab2.c[0]);
+                std::fill(c->used1.begin(), c->used1.end(), u1);
+                std::fill(c->used2.begin(), c->used2.end(), u2);
+                c->gmask1 = u1 >= 1 ? ~0u : 0u;
+                c->gmask2 = u2 >= 1 ? ~0u : 0u;
+            }
         }
         VCHCHK(newton_level(c, dt[step], un, unp1, hs, nullptr, true));
         // clip, mass fix, store (F2:562-585)
@@ -1412,40 +1449,51 @@ static int forward_core(vch2d_ctx *c, const double *u_dev, int u_rows, const dou
         LAUNCH(k_post, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s,
                hist_out ? hist_out + (long)(step + 1) * c->G.plane : (double *)nullptr, hs, (const double *)c->part);
         std::swap(c->w, c->wnew);
-        if (c->guess_on && c->guess_c[0] != 0.0) {
-            // what this guess achieved (worst trajectory that solved) decides the order of the next one (GuessPolicy)
-            double worst = 0.0;
-            bool any = false;
-            for (int b = 0; b < c->B; ++b) {
-                const TrajState &S = c->st_host[b];
-                if (S.frozen || S.step_solves < 1) continue;
-                any = true;
-                worst = std::max(worst, std::isfinite(S.guess_ratio) ? S.guess_ratio : 1e300);
-            }
-            if (any) c->guess_pol.report(worst, c->guess_used, c->guess_max);
-        }
-        if (c->guess_on && c->guess2_on) {
-            // second solves: the ring is usable while every marching trajectory takes one, step after step
-            bool all2 = true, anyb = false;
-            double worst2 = 0.0;
-            for (int b = 0; b < c->B; ++b) {
-                const TrajState &S = c->st_host[b];
-                if (S.frozen) continue;
-                anyb = true;
-                if (S.step_solves < 2) all2 = false;
-                worst2 = std::max(worst2, std::isfinite(S.guess_ratio2) ? S.guess_ratio2 : 1e300);
-            }
-            if (anyb && all2) {
-                c->guess_run2++;
-                if (c->guess_used2 >= 1) c->guess_pol2.report(worst2, c->guess_used2, c->guess_max);
+        if (c->guess_on) {
+            // what each guess achieved decides the order of that trajectory's next one (GuessPolicy); the second solves' ring
+            // is usable while the trajectory takes a second solve step after step
+            auto fin = [](double r) { return std::isfinite(r) ? r : 1e300; };
+            if (per_traj) {
+                for (int b = 0; b < c->B; ++b) {
+                    const TrajState &S = c->st_host[b];
+                    if (S.frozen) continue;
+                    if (c->used1[b] >= 1 && S.step_solves >= 1) c->pol1[b].report(fin(S.guess_ratio), c->used1[b], c->guess_max);
+                    if (!c->guess2_on) continue;
+                    if (S.step_solves >= 2) {
+                        c->run2[b]++;
+                        if (c->used2[b] >= 1) c->pol2[b].report(fin(S.guess_ratio2), c->used2[b], c->guess_max);
+                    } else {
+                        c->run2[b] = 0;
+                        c->pol2[b].reset();
+                    }
+                }
             } else {
-                c->guess_run2 = 0;
-                c->guess_pol2.reset();
+                double worst = 0.0, worst2 = 0.0;
+                bool any = false, anyb = false, all2 = true;
+                for (int b = 0; b < c->B; ++b) {
+                    const TrajState &S = c->st_host[b];
+                    if (S.frozen) continue;
+                    anyb = true;
+                    if (S.step_solves >= 1) { any = true; worst = std::max(worst, fin(S.guess_ratio)); }
+                    if (S.step_solves < 2) all2 = false;
+                    worst2 = std::max(worst2, fin(S.guess_ratio2));
+                }
+                if (any && c->used1[0] >= 1) c->pol1_all.report(worst, c->used1[0], c->guess_max);
+                if (c->guess2_on) {
+                    if (anyb && all2) {
+                        c->run2_all++;
+                        if (c->used2[0] >= 1) c->pol2_all.report(worst2, c->used2[0], c->guess_max);
+                    } else {
+                        c->run2_all = 0;
+                        c->pol2_all.reset();
+                    }
+                }
             }
         }
     }
-    for (double &g : c->guess_c) g = 0.0;
-    for (double &g : c->guess_c2) g = 0.0;
+    memset(c->gtab1.c, 0, sizeof(c->gtab1.c));
+    memset(c->gtab2.c, 0, sizeof(c->gtab2.c));
+    c->gmask1 = c->gmask2 = 0;
     c->guess_wr = -1;
     return 0;
 }
@@ -1490,7 +1538,7 @@ extern "C" int vch2d_forward(vch2d_ctx *c, const double *phi0, const double *u, 
 // host looks at the device state only every ADJ_LOOK steps and enqueues (longest solve so far) + 1 sweeps per step, within
 // the rigorous bound; solves are gated per trajectory, and one that its sweeps did not finish is counted on the device
 // (lin_unconv).  safe = true: a look and the rigorous budget at every step (the fallback of backward_core).
-constexpr int ADJ_LOOK = 8;
+constexpr int ADJ_LOOK = 8, ADJ_SETTLE = 16;
 static int backward_pass(vch2d_ctx *c, const double *phi_hist_dev, int M, const double *t_hist, double b1, double b2,
                          const double *phiQ_dev, const double *phiT_dev, double *r_out, double *p_out, double *q_out, bool safe) {
     const long hs = hist_stride(c);
@@ -1508,8 +1556,11 @@ static int backward_pass(vch2d_ctx *c, const double *phi_hist_dev, int M, const 
     // starting guess of the solve for p_n (k_adj_guess; the forward ring dprev is free during the sweep): polynomial
     // extrapolation in time over the levels n+2, n+4, .. n+2*order already solved.  order grows by one per look while the
     // guess keeps paying, and the looks come every step until it has settled
-    const bool guess = c->guess_on && !safe && !getenv("VCH_ADJ_GUESS_OFF");
-    int order = 1, kept = 0, settled = 0;
+    const bool guess = c->guess_on && !safe && !c->adj_guess_off;
+    // the order is every trajectory's own (raised / lowered on its own ratios); batches beyond GUESS_BMAX share entry 0
+    const bool per_traj = c->B <= GUESS_BMAX;
+    std::vector<int> order(per_traj ? c->B : 1, 1);
+    int kept = 0;
     LAUNCH(k_adj_finish, c->grid, dim3(NTH), G, c->x, (const double *)nullptr, qa, rcur, 0.0, 0.0,
            r_out ? r_out + (long)M * G.plane : (double *)nullptr, p_out ? p_out + (long)M * G.plane : (double *)nullptr,
            q_out ? q_out + (long)M * G.plane : (double *)nullptr, hs);
@@ -1529,26 +1580,36 @@ static int backward_pass(vch2d_ctx *c, const double *phi_hist_dev, int M, const 
                phi_hist_dev + (long)(n + 1) * G.plane, phiQ_dev ? phiQ_dev + (long)n * G.plane : (const double *)nullptr,
                phiQ_dev ? phiQ_dev + (long)(n + 1) * G.plane : (const double *)nullptr, hs, dtn, b1, rhs, Dn, c->part);
         LAUNCH(k_fin_lin_begin, dim3(c->B), dim3(64), c->st, c->part, c->nblk, 0, c->P.tau, c->P.kappa, dtn, c->lin_tol);
-        if (safe || steps_since_look >= (guess && settled < 2 ? 1 : ADJ_LOOK) || sweeps < 0) {
+        // looks at levels fixed in advance (every level for the first ADJ_SETTLE ones, where the orders of the guesses are
+        // being raised, then every ADJ_LOOK-th): when a trajectory's order changes depends on its own ratios only
+        if (safe || steps_since_look >= ((guess && M - 1 - n < ADJ_SETTLE) ? 1 : ADJ_LOOK) || sweeps < 0) {
             VCHCHK(sync_state(c, false));
             steps_since_look = 0;
             int longest = 0;
-            double worst = 0.0;
-            for (int b = 0; b < c->B; ++b) {
-                longest = std::max(longest, c->st_host[b].step_lin_max);
-                worst = std::max(worst, std::isfinite(c->st_host[b].guess_ratio) ? c->st_host[b].guess_ratio : 1e300);
-            }
+            for (int b = 0; b < c->B; ++b) longest = std::max(longest, c->st_host[b].step_lin_max);
             const int bound = cg_budget(c, false);
             int margin = 1;
             if (guess && !first_solve) {
-                // the state shows the solve of the previous level, started from a guess of the current order
-                const int before = order;
-                if (worst < 0.25) order = std::min(order + 1, GUESS_ORD / 2);
-                else if (worst > 0.7) order = std::max(order - 1, 1);
-                settled = order == before ? settled + 1 : 0;
-                if (order != before) margin = 2;
-                if (getenv("VCH_DEBUG_GUESS"))
-                    fprintf(stderr, "adjoint level %d: order %d -> %d ratio %.3e longest %d\n", n, before, order, worst, longest);
+                // the state shows the solve of the previous level, started from a guess of the trajectory's current order
+                bool changed = false;
+                auto adapt = [&](int &ord, double ratio) {
+                    const int before = ord;
+                    if (ratio < 0.25) ord = std::min(ord + 1, GUESS_ORD / 2);
+                    else if (ratio > 0.7) ord = std::max(ord - 1, 1);
+                    changed |= ord != before;
+                };
+                auto fin = [](double r) { return std::isfinite(r) ? r : 1e300; };
+                if (per_traj) {
+                    for (int b = 0; b < c->B; ++b) adapt(order[b], fin(c->st_host[b].guess_ratio));
+                } else {
+                    double worst = 0.0;
+                    for (int b = 0; b < c->B; ++b) worst = std::max(worst, fin(c->st_host[b].guess_ratio));
+                    adapt(order[0], worst);
+                }
+                if (changed) margin = 2;
+                if (c->debug_guess)
+                    fprintf(stderr, "adjoint level %d: order (traj 0) %d ratio %.3e longest %d\n", n, order[0],
+                            c->st_host[0].guess_ratio, longest);
                 LAUNCH(k_reset_longest, dim3((c->B + 63) / 64), dim3(64), c->st, c->B);     // longest = since this look
             }
             // the first solve of the sweep has nothing to go by: rigorous bound, with looks
@@ -1558,28 +1619,29 @@ static int backward_pass(vch2d_ctx *c, const double *phi_hist_dev, int M, const 
         if (guess) {
             // c->x = p_{n+1} goes into the ring (slot kept mod GUESS_RING); level n+1+j was kept j saves ago.  The guess is
             // the polynomial through the levels n+2k, k = 1..m, at t_n; nothing kept yet: p_{n+1} as it stands
-            const int m = std::min(order, (kept + 1) / 2);
             GuessArgs ga;
-            for (int j = 0; j < GUESS_ORD; ++j) {
-                ga.c[j] = 0.0;
-                ga.d[j] = c->dprev[(kept - j) & (GUESS_RING - 1)];
-            }
-            int mu = m;
-            for (; mu >= 1; --mu) {                      // weights of large magnitude (ragged time grids): a lower order
-                double mag = 0.0;
-                for (int j = 0; j < GUESS_ORD; ++j) ga.c[j] = 0.0;
-                for (int j = 1; j <= mu; ++j) {
-                    double w = 1.0;
-                    for (int k = 1; k <= mu; ++k)
-                        if (k != j) w *= (t_hist[n] - t_hist[n + 2 * k]) / (t_hist[n + 2 * j] - t_hist[n + 2 * k]);
-                    ga.c[2 * j - 1] = w;
-                    mag += std::fabs(w);
+            memset(ga.c, 0, sizeof(ga.c));
+            ga.per_traj = per_traj ? 1 : 0;
+            for (int j = 0; j < GUESS_ORD; ++j) ga.d[j] = c->dprev[(kept - j) & (GUESS_RING - 1)];
+            for (size_t b = 0; b < order.size(); ++b) {
+                double *cf = ga.c[b];
+                int mu = std::min(order[b], (kept + 1) / 2);
+                for (; mu >= 1; --mu) {                      // weights of large magnitude (ragged time grids): a lower order
+                    double mag = 0.0;
+                    for (int j = 0; j < GUESS_ORD; ++j) cf[j] = 0.0;
+                    for (int j = 1; j <= mu; ++j) {
+                        double w = 1.0;
+                        for (int k = 1; k <= mu; ++k)
+                            if (k != j) w *= (t_hist[n] - t_hist[n + 2 * k]) / (t_hist[n + 2 * j] - t_hist[n + 2 * k]);
+                        cf[2 * j - 1] = w;
+                        mag += std::fabs(w);
+                    }
+                    if (std::isfinite(mag) && mag <= 64.0) break;
                 }
-                if (std::isfinite(mag) && mag <= 64.0) break;
-            }
-            if (mu == 0) {
-                for (int j = 0; j < GUESS_ORD; ++j) ga.c[j] = 0.0;
-                ga.c[0] = 1.0;                           // p_{n+1} as it stands
+                if (mu == 0) {
+                    for (int j = 0; j < GUESS_ORD; ++j) cf[j] = 0.0;
+                    cf[0] = 1.0;                             // p_{n+1} as it stands
+                }
             }
             LAUNCHC(PC_ADJ_GUESS, k_adj_guess, c->grid, dim3(NTH), G, c->x, ga, c->dprev[kept & (GUESS_RING - 1)]);
             ++kept;
@@ -1596,19 +1658,32 @@ static int backward_pass(vch2d_ctx *c, const double *phi_hist_dev, int M, const 
 
 static int backward_core(vch2d_ctx *c, const double *phi_hist_dev, int M, const double *t_hist, double b1, double b2,
                          const double *phiQ_dev, const double *phiT_dev, double *r_out, double *p_out, double *q_out) {
-    if (getenv("VCH_ADJ_SAFE"))       // diagnostics: the fallback schedule (a look and the rigorous budget at every step)
+    c->adj_guess_off = getenv("VCH_ADJ_GUESS_OFF") != nullptr;
+    c->adj_safe = getenv("VCH_ADJ_SAFE") != nullptr;
+    if (c->adj_safe)                  // diagnostics: the fallback schedule (a look and the rigorous budget at every step)
         return backward_pass(c, phi_hist_dev, M, t_hist, b1, b2, phiQ_dev, phiT_dev, r_out, p_out, q_out, true);
+    c->redo_iters = 0;
     VCHCHK(backward_pass(c, phi_hist_dev, M, t_hist, b1, b2, phiQ_dev, phiT_dev, r_out, p_out, q_out, false));
     VCHCHK(sync_state(c));
     bool redo = false;
+    long iters = 0;
+    const double accept = 10.0 * c->lin_tol;
     for (int b = 0; b < c->B; ++b) {
         const TrajState &S = c->st_host[b];
-        // a solve that ran out of sweeps above round-off level: the schedule was too short somewhere
-        if ((S.lin_unconv > 0 && S.lin_maxrel > 1e-12) || (S.lin_active && S.lin_rel > 1e-12)) redo = true;
+        iters += S.lin_total;
+        // a solve that ran out of sweeps above the solve tolerance's class: the schedule was too short somewhere
+        if ((S.lin_unconv > 0 && S.lin_maxrel > accept) || (S.lin_active && S.lin_rel > accept)) redo = true;
     }
     if (!redo) return 0;
+    const long syncs = c->n_sync, launches = c->n_launch;
     VCHCHK(reset_counters(c));
-    return backward_pass(c, phi_hist_dev, M, t_hist, b1, b2, phiQ_dev, phiT_dev, r_out, p_out, q_out, true);
+    VCHCHK(backward_pass(c, phi_hist_dev, M, t_hist, b1, b2, phiQ_dev, phiT_dev, r_out, p_out, q_out, true));
+    c->redo_iters = iters;                     // the first pass stays in the books (fill_stats, counters)
+    c->n_sync += syncs;
+    c->n_launch += launches;
+    c->tot_sync -= syncs;
+    c->tot_launch -= launches;
+    return 0;
 }
 
 extern "C" int vch2d_backward(vch2d_ctx *c, const double *phi_hist, int M, const double *t_hist, double hx, double hy,

@@ -647,6 +647,7 @@ __global__ __launch_bounds__(NTH) void k_dmu_ceiling_fin(Geom G, Phys P, TrajSta
                                                          double *__restrict__ x_keep, double *__restrict__ x_keep2) {
     TILE_COORDS;
     if (!st[b].newton_active || st[b].need_trial) return;
+    if (st[b].use_cheb) return;           // solved in the reduction-free form: its last row kernel did this kernel's work
     __shared__ double sx[(TY + 2) * (TX + 2)];
     __shared__ double sred[NPART * 4];
     __shared__ double s3[3];
@@ -709,7 +710,7 @@ __global__ __launch_bounds__((FftThreads<C, LOGL>::T)) void k_cg_rows_fwd(Geom G
     if (FIRST) {
         // start of a solve (what k_fin_cg_init does on the GEMM path): workgroup 0 of the trajectory sums
         // gamma0 = <z0,z0>_Z from the partials of the transform that produced z0 and arms the per-sweep state
-        const int active = st[b].lin_active;
+        const int active = st[b].lin_active && !st[b].use_cheb;
         if (blockIdx.x == 0 && tid < 64) {
             double g = 0.0;
             if (active)
@@ -908,7 +909,7 @@ __global__ __launch_bounds__((FftThreads<C, LOGL>::T)) void k_cheb_rows(Geom G, 
     const int b = blockIdx.z;
     ChebSweepArgs a = a_;
     if (FIRST) a.j = 0;
-    if (!st[b].lin_active || a.j > st[b].cheb_n) return;
+    if (!st[b].lin_active || !st[b].use_cheb || a.j > st[b].cheb_n) return;
     const bool last = a.j == st[b].cheb_n;
     __shared__ double2 buf[FftLds<C>::SIZE];
     constexpr int T = FftThreads<C, LOGL>::T;

@@ -59,8 +59,11 @@ struct TrajState {
     // reduction-free (Chebyshev) form of the forward solve (vch_fft.h, k_cheb_rows): spec(P^-1 A) in [theta - delta,
     // theta + delta] = [1, kT] and the number of sweeps after which the rigorous bound 1 / T_{n+1}(theta/delta) is below
     // the solve's tolerance -- all known before the solve starts, so no inner product steers it
-    int cheb_n, cheb_pad;
+    int cheb_n;
+    int use_cheb;              // THIS solve takes the reduction-free form (its plan is short): decided per trajectory and per
+                               // solve on the device, so a trajectory's arithmetic does not depend on its batch mates
     double cheb_theta, cheb_delta;
+    int step_form[4];          // use_cheb of the step's first four solves (host: which launch sequences the next step needs)
     int lin_took, lin_unconv;  // adjoint: this solve started (its y is valid); solves the enqueued sweeps did not finish
     int cg_pending, cg_pbuf, cg_pad;   // forward CG: step (alpha, p[cg_pbuf]) computed but not yet added to x
     // forward CG, per-iteration state in two copies: iteration k's stencil kernel derives the step of
@@ -77,8 +80,11 @@ struct TrajState {
 // gate codes of the preconditioner kernels: 1 = lin_active, 2 / 3 = copy 0 / 1 of the forward CG's per-iteration flag
 // 4 = the adjoint solve of this step took place (lin_took)
 // 16 + j = the column pass in front of sweep j of a Chebyshev solve (the trajectory is solving and needs that sweep)
+// 5 = solving in the CG form (lin_active and not use_cheb), 8 = solving in the reduction-free form
 __device__ __forceinline__ bool gate_open(const TrajState &S, int gate) {
-    if (gate >= 16) return S.lin_active != 0 && gate - 16 <= S.cheb_n;
+    if (gate >= 16) return S.lin_active != 0 && S.use_cheb != 0 && gate - 16 <= S.cheb_n;
+    if (gate == 5) return S.lin_active != 0 && S.use_cheb == 0;
+    if (gate == 8) return S.lin_active != 0 && S.use_cheb != 0;
     return gate == 1 ? S.lin_active != 0 : (gate == 4 ? S.lin_took != 0 : S.ci_active[gate - 2] != 0);
 }
 
@@ -261,6 +267,8 @@ __device__ __forceinline__ void newton_begin(TrajState &S) {
     S.step_lin_max = 0;
     S.step_lin[0] = S.step_lin[1] = S.step_lin[2] = S.step_lin[3] = 0;
     S.step_chn[0] = S.step_chn[1] = S.step_chn[2] = S.step_chn[3] = 0;
+    S.step_form[0] = S.step_form[1] = S.step_form[2] = S.step_form[3] = 0;
+    S.use_cheb = 0;
     S.x_primed = 0;
     S.lin_rscale = 1.0;
     S.guess_ratio = 1.0;
@@ -524,10 +532,17 @@ __global__ __launch_bounds__(NTH) void k_schur(Geom G, Phys P, const TrajState *
 // ---------------------------------------------------------------------------------
 constexpr int GUESS_RING = 8;     // increments kept (a power of two)
 constexpr int GUESS_ORD = 8;      // at most this many planes enter one guess (forward: <= 6 increments; adjoint: every second level)
+constexpr int GUESS_BMAX = 32;    // trajectories per context with coefficients of their own (beyond: one common set, row 0)
 struct GuessArgs {
     const double *d[GUESS_ORD];   // first Newton increments of steps n-1 .. n-GUESS_ORD, [B][plane]
-    double c[GUESS_ORD];          // their coefficients (0 = plane not used)
+    // their coefficients (0 = plane not used), PER TRAJECTORY: the order of the extrapolation is chosen for every
+    // trajectory from its own history (forward_core), so a trajectory's arithmetic does not depend on its batch mates
+    double c[GUESS_BMAX][GUESS_ORD];
+    int per_traj;                 // 0: row 0 holds for every trajectory
+    __host__ __device__ const double *row(int b) const { return c[per_traj ? b : 0]; }
 };
+// bit b of the mask a fin kernel gets: trajectory b's right-hand side was deflated by a starting guess in this launch sequence
+__host__ __device__ inline unsigned guess_bit(unsigned mask, int b) { return (mask >> (b & 31)) & 1u; }
 // which = 0: the step's first solve (right-hand side of the initial residual, iterate slot S.slot);  which = 1: its second
 // solve -- the kernel sits between a trial's k_residual<1> and k_fin_residual<1>, works on the slot the trial wrote
 // (1 - S.slot) and only for trajectories whose first solve is done (iters == 1); a trial that is then rejected
@@ -540,6 +555,8 @@ __global__ __launch_bounds__(NTH) void k_guess(Geom G, Phys P, const TrajState *
     const TrajState S = st[b];
     if (!S.newton_active || !S.need_trial) return;
     if (which == 1 && S.iters != 1) return;
+    const double *gcf = ga.row(b);
+    if (gcf[0] == 0.0) return;             // no guess for this trajectory in this step
     const int slot = which == 1 ? 1 - S.slot : S.slot;
     __shared__ double sx[(TY + 4) * (TX + 4)];
     __shared__ double stt[(TY + 2) * (TX + 2)];
@@ -550,10 +567,10 @@ __global__ __launch_bounds__(NTH) void k_guess(Geom G, Phys P, const TrajState *
         int ly = e / W2, lxx = e - ly * W2;
         int gr = refl(r0 - 2 + ly, G.ns), gc = refl(c0 - 2 + lxx, G.nf);
         long o = pb + (long)gr * G.pitch + gc;
-        double v = ga.c[0] * ga.d[0][o];
+        double v = gcf[0] * ga.d[0][o];
 #pragma unroll
         for (int j = 1; j < GUESS_ORD; ++j)
-            if (ga.c[j] != 0.0) v += ga.c[j] * ga.d[j][o];
+            if (gcf[j] != 0.0) v += gcf[j] * ga.d[j][o];
         sx[e] = isfinite(v) ? v : 0.0;
     }
     __syncthreads();
@@ -1156,11 +1173,12 @@ __device__ __forceinline__ double cheb_last_factor(double theta, double delta, i
 
 template <int MODE>
 __device__ __forceinline__ void fin_residual_update(TrajState &S, const double (&v)[NPART], bool primed, double *__restrict__ hist,
-                                                    double kappa, double dt, double lin_tol, double eta);
+                                                    double kappa, double dt, double lin_tol, double eta, int cheb_max);
 
 template <int MODE>
 __global__ void k_fin_residual(TrajState *st, const double *__restrict__ part, int nblk,
-                               double *__restrict__ hist, double kappa, double dt, double lin_tol, double eta, int guess) {
+                               double *__restrict__ hist, double kappa, double dt, double lin_tol, double eta, int guess,
+                               int cheb_max) {
     const int b = blockIdx.x;
     // the record is worked on in registers and written back once: through a reference every field access is a global
     // memory round trip and the state machine below a chain of them (one workgroup, nothing to hide them behind)
@@ -1175,16 +1193,17 @@ __global__ void k_fin_residual(TrajState *st, const double *__restrict__ part, i
     const int op[NPART] = {0, 0, 1, 2, 0, 0};
     // guess: k_guess has deflated the right-hand side (MODE 0: of the step's first solve; MODE 1: of its second solve, for
     // a trajectory whose first solve is done); slot 1 holds sum (rhs - A x0)^2, slot 4 sum rhs^2
-    const bool primed = guess && (MODE != 1 || S.iters == 1);
+    const bool primed = guess_bit((unsigned)guess, b) && (MODE != 1 || S.iters == 1);
     fin_reduce(part, nblk, b, v, op, primed ? 5 : 4);
     if (threadIdx.x != 0) return;
-    fin_residual_update<(MODE == 1 ? 1 : 0)>(S, v, primed, hist + (long)b * HIST_CAP, kappa, dt, lin_tol, eta);
+    fin_residual_update<(MODE == 1 ? 1 : 0)>(S, v, primed, hist + (long)b * HIST_CAP, kappa, dt, lin_tol, eta, cheb_max);
     st[b] = S;
 }
 
+// cheb_max: plans of at most that many sweeps take the reduction-free form (-1: never, the CG form always)
 template <int MODE>
 __device__ __forceinline__ void fin_residual_update(TrajState &S, const double (&v)[NPART], bool primed, double *__restrict__ hist,
-                                                    double kappa, double dt, double lin_tol, double eta) {
+                                                    double kappa, double dt, double lin_tol, double eta, int cheb_max) {
     const double nt = sqrt(v[0]);
     bool accept;
     if (MODE == 0) {
@@ -1224,6 +1243,7 @@ __device__ __forceinline__ void fin_residual_update(TrajState &S, const double (
         S.lin_reltol = newton_lin_tol(S.lin_r0, lin_tol, eta);
         cg_setup(S, 2.0 * sqrt(0.5 * kappa / dt), 1.0, S.lin_reltol);
         cheb_plan(S, S.lin_reltol);
+        S.use_cheb = (cheb_max >= 0 && S.cheb_n <= cheb_max) ? 1 : 0;
         S.lin_active = 1;
         S.lin_it = 0;
         S.lin_prev = 1e300;
@@ -1234,6 +1254,7 @@ __device__ __forceinline__ void fin_residual_update(TrajState &S, const double (
             S.step_tol[S.step_solves - 1] = S.lin_reltol;
             S.step_kT[S.step_solves - 1] = S.kT;
             S.step_chn[S.step_solves - 1] = S.cheb_n;
+            S.step_form[S.step_solves - 1] = S.use_cheb;
         }
         // (a zero right-hand side is not special-cased: the solve starts, zeroes x and ends at its first reduction point)
     } else {
@@ -1275,6 +1296,7 @@ struct EvalFin {
     unsigned *counter;         // [B], zero between launches
     double *hist;              // [B][HIST_CAP] residual-norm histories
     double kappa, lin_tol, eta;
+    int cheb_max;
 };
 
 __device__ __forceinline__ void store_agent(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -1335,7 +1357,8 @@ __global__ __launch_bounds__(NTH, EVAL_MINBLK) void k_eval(Geom G, Phys P, TrajS
     // land where a neighbouring workgroup may still be loading the halo of the old one
     const int src = S_slot, dst = 1 - S_slot;
     const double tdt = P.tau / dt;
-    const bool do_guess = ga.c[0] != 0.0 && (MODE == 0 || S_iters == 1);
+    const double *gcf = ga.row(b);
+    const bool do_guess = gcf[0] != 0.0 && (MODE == 0 || S_iters == 1);
     double rm[TY / 4], rh[TY / 4];
     double acc[5] = {0.0, 0.0, 1e300, -1e300, 0.0};
     if (MODE == 0) {
@@ -1471,10 +1494,10 @@ __global__ __launch_bounds__(NTH, EVAL_MINBLK) void k_eval(Geom G, Phys P, TrajS
             int ly = e / W2, lxx = e - ly * W2;
             int gr = refl(r0 - 2 + ly, G.ns), gc = refl(c0 - 2 + lxx, G.nf);
             long o = pb + (long)gr * G.pitch + gc;
-            double v = ga.c[0] * ga.d[0][o];
+            double v = gcf[0] * ga.d[0][o];
 #pragma unroll
             for (int j = 1; j < GUESS_ORD; ++j)
-                if (ga.c[j] != 0.0) v += ga.c[j] * ga.d[j][o];
+                if (gcf[j] != 0.0) v += gcf[j] * ga.d[j][o];
             X[e] = isfinite(v) ? v : 0.0;
         }
         __syncthreads();
@@ -1547,7 +1570,8 @@ __global__ __launch_bounds__(NTH, EVAL_MINBLK) void k_eval(Geom G, Phys P, TrajS
             newton_begin(S);
             S.slot = dst;                         // the evaluated start iterate lives there (a trial flips the slot when accepted)
         }
-        fin_residual_update<(MODE == 0 ? 0 : 1)>(S, v, do_guess, fin.hist + (long)b * HIST_CAP, fin.kappa, dt, fin.lin_tol, fin.eta);
+        fin_residual_update<(MODE == 0 ? 0 : 1)>(S, v, do_guess, fin.hist + (long)b * HIST_CAP, fin.kappa, dt, fin.lin_tol, fin.eta,
+                                                 fin.cheb_max);
         st[b] = S;
     }
 }
@@ -1740,6 +1764,7 @@ __global__ void k_fin_ceiling(TrajState *st, const double *__restrict__ part, in
     const int b = blockIdx.x;
     TrajState S = st[b];                    // in registers, written back once (see k_fin_residual)
     if (!S.newton_active || S.need_trial) return;
+    if ((cheb.enq >= 0) != (S.use_cheb != 0)) return;      // the other form's launch sequence looks after this trajectory
     if (cheb.enq >= 0 && S.lin_active) {
         if (S.cheb_n > cheb.enq) return;    // unfinished: taken up again by the next solve slot / the host's loop
         double rel = 1.0;
@@ -1842,6 +1867,7 @@ __global__ void k_fin_lin_begin(TrajState *st, const double *__restrict__ part, 
     S.lin_prev = 1e300;
     S.lin_rel = 1.0;
     S.lin_reltol = lin_tol;
+    S.use_cheb = 0;
     S.nsolves++;
 }
 
@@ -1928,10 +1954,11 @@ __global__ __launch_bounds__(NTH) void k_adj_guess(Geom G, double *__restrict__ 
         if (r < G.ns && c < G.nf) {
             const long o = b * G.plane + (long)r * G.pitch + c;
             const double p1 = x[o];
-            double v = ga.c[0] * p1;
+            const double *gcf = ga.row(b);
+            double v = gcf[0] * p1;
 #pragma unroll
             for (int j = 1; j < GUESS_ORD; ++j)
-                if (ga.c[j] != 0.0) v += ga.c[j] * ga.d[j][o];
+                if (gcf[j] != 0.0) v += gcf[j] * ga.d[j][o];
             keep[o] = p1;
             x[o] = isfinite(v) ? v : p1;
         }

@@ -37,7 +37,7 @@ def test_every_declared_symbol_is_exported_and_bound(V):
 
 def test_abi_version_and_error_string(V):
     lib = V.load()
-    assert lib.vch_abi_version() == 2
+    assert lib.vch_abi_version() == 3
     assert isinstance(lib.vch_last_error(), bytes)
 
 

@@ -364,8 +364,10 @@ def test_pgd_batch_matches_single(V, O2):
     for b in range(3):
         e1.pgd_init(phi0[b], phi_T, t, opt, ramp=True, T=T)
         r1 = e1.pgd_iterate(2)
-        assert np.allclose(r3["cost"][b], r1["cost"][0], rtol=1e-12)
-        assert relerr(u3[b], e1.pgd_get("u")) < 1e-10
+        # bit for bit: every decision that shapes a trajectory's arithmetic (form and length of its solves, orders of its
+        # starting guesses) is taken per trajectory from its own history
+        assert np.array_equal(r3["cost"][b], r1["cost"][0])
+        assert np.array_equal(u3[b], e1.pgd_get("u"))
 
 
 def test_pgd_batch_uneven_line_search(V, O2):
@@ -390,11 +392,10 @@ def test_pgd_batch_uneven_line_search(V, O2):
         e1.pgd_init(phi0[b], phi_T[b], t, opt, ramp=True, T=T)
         r1 = e1.pgd_iterate(4)
         assert np.array_equal(r4["attempts"][b], r1["attempts"][0])
-        # equal to the tolerance of the inexact Newton solves, not to round-off: the order of the solves' starting guess is
-        # chosen per batch (from its worst trajectory), so a trajectory's solves start from different guesses with
-        # different batch mates and end anywhere inside the same residual target
-        assert np.allclose(r4["cost"][b], r1["cost"][0], rtol=1e-10)
-        assert relerr(u4[b], e1.pgd_get("u")) < 2e-9 and relerr(p4[b], e1.pgd_get("phi")) < 2e-9
+        # ... bit for bit, although its batch mates sit out different trial marches and their solves take other forms and
+        # lengths: nothing in a trajectory's arithmetic depends on them (round 2: equal to the solves' tolerance only)
+        assert np.array_equal(r4["cost"][b], r1["cost"][0])
+        assert np.array_equal(u4[b], e1.pgd_get("u")) and np.array_equal(p4[b], e1.pgd_get("phi"))
 
 
 # ---------------------------------------------------------------------------------------
@@ -531,6 +532,49 @@ def test_full_size_pgd_iteration_invariants_512x1000(V, O2):
     assert np.abs(mass - mass[0]).max() <= 1e-10 * np.sum(wts)
     assert np.abs(ph).max() <= 0.99 + 1e-15
 
+
+
+def test_config4_shape_two_contexts_of_four_512(V, O2):
+    """The benched shape of BASELINE config 4 on one GPU: 512^2, 8 trajectories (seeds 42..49) as two contexts of 4 running
+    concurrently (one host thread each, as bench.py drives them), a short horizon (40 steps of 1e-3) and two PGD
+    iterations; every trajectory reproduces its own single-trajectory run BIT FOR BIT -- costs, step lengths, line-search
+    attempts, control and state -- so a seed gives the same iterates whatever the batch, context or GPU it lands in."""
+    import threading
+    F2 = V.module("Vch_control_2D.Forward2_solver")
+    N, M = 512, 40
+    t, dts = V.time_grid(M * 1e-3, 1e-3)
+    xs = np.linspace(0, 1, N + 1)
+    phi_T = 0.7 * np.sin(2 * np.pi * xs)[:, None] * np.cos(np.pi * xs)[None, :]
+    phi0 = np.stack([F2.init_phi_random(N, N, 1e-2, amp=0.1, seed=42 + i) for i in range(8)])
+    opt = V.make_opt()
+    engs = [V.Engine2D(Nx=N, Ny=N, batch=4, max_steps=M) for _ in range(2)]
+    out = [None, None]
+
+    def work(k):
+        e = engs[k]
+        J0 = e.pgd_init(phi0[4 * k:4 * k + 4], np.stack([phi_T] * 4), t, opt, ramp=True, T=M * 1e-3)
+        r = e.pgd_iterate(2)
+        out[k] = (J0, r, e.pgd_get("u"), e.pgd_get("phi"))
+    ths = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    for e in engs:
+        e.close()
+    assert all(o is not None for o in out)
+    e1 = V.Engine2D(Nx=N, Ny=N, batch=1, max_steps=M)
+    for i in range(8):
+        J0, r, u, ph = out[i // 4]
+        b = i % 4
+        J1 = e1.pgd_init(phi0[i], phi_T, t, opt, ramp=True, T=M * 1e-3)
+        r1 = e1.pgd_iterate(2)
+        assert np.array_equal(J0[b], J1[0]), i
+        assert np.array_equal(r["attempts"][b], r1["attempts"][0]) and np.array_equal(r["alpha"][b], r1["alpha"][0]), i
+        assert np.array_equal(r["cost"][b], r1["cost"][0]), (i, r["cost"][b], r1["cost"][0])
+        assert np.array_equal(u[b], e1.pgd_get("u")) and np.array_equal(ph[b], e1.pgd_get("phi")), i
+        assert np.all(np.diff(np.concatenate([J1[0, 4:5], r1["cost"][0]])) < 0)
+    e1.close()
 
 
 def test_bitwise_reproducibility(V, O2):
