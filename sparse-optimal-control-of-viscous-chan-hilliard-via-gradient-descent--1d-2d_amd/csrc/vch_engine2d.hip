@@ -109,6 +109,7 @@ struct vch2d_ctx {
     int fused_mode;                       // 0 separate kernels, 1 fused with the fin step inside, 2 fused + fin launches
     unsigned *fin_counter;
     int cheb_enq, spec_chn[4], cheb_margin, cheb_max;
+    double cg_scale_ratio;                // CG form: Dmax / Dmin beyond which a solve runs right-scaled (0 = never; VCH_CG_SCALE)
     // starting guess of a step's first Newton solve (k_guess): the first increments of the last GUESS_RING steps (ring,
     // written by k_dmu_ceiling_fin; the adjoint sweep keeps its levels there instead), the guess itself (also that of the
     // second solve), its coefficients for the step being enqueued (all 0 = no guess) and the ring slot this step's
@@ -411,6 +412,8 @@ extern "C" vch2d_ctx *vch2d_create(const vch2d_params *p, int batch, int max_ste
     if (const char *e = getenv("VCH_CHEB_MARGIN")) c->cheb_margin = std::max(0, atoi(e));
     c->cheb_max = 6;           // plans longer than this (a wide spectrum: CG's adaptivity pays) keep the CG form
     if (const char *e = getenv("VCH_CHEB_MAX")) c->cheb_max = std::max(0, atoi(e));
+    c->cg_scale_ratio = 4.0;
+    if (const char *e = getenv("VCH_CG_SCALE")) c->cg_scale_ratio = atof(e);
     c->n_launch = c->n_sync = 0;
     auto fail = [&](const char *what) {
         vch_fail(VCH_ERR_HIP, "vch2d_create: %s failed: %s", what, hipGetErrorString(hipGetLastError()));
@@ -883,7 +886,7 @@ static int dmu_ceiling(vch2d_ctx *c, int strict) {
                     (const double *)nullptr, (const double *)nullptr, 0L, (double *)nullptr, gt_, c->x0g, efin_);           \
             if (!fin_inside)                                                                                                \
                 LAUNCH((k_fin_residual<1>), dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->hist_dev, c->P.kappa, dt,     \
-                       c->lin_tol, eta_, tg_ ? (int)c->gmask2 : 0, cheb_max_);                                              \
+                       c->lin_tol, eta_, tg_ ? (int)c->gmask2 : 0, so_);                                              \
             break;                                                                                                          \
         }                                                                                                                   \
         if (inline_dmu)                                                                                                     \
@@ -896,7 +899,7 @@ static int dmu_ceiling(vch2d_ctx *c, int strict) {
             LAUNCHC(PC_GUESS, k_guess, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->gtab2,                     \
                     (const double *)c->D_s, dt, c->rhs_s, c->x0g, c->part, 1);                                              \
         LAUNCH((k_fin_residual<1>), dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->hist_dev, c->P.kappa, dt, c->lin_tol, \
-               eta_, tg_ ? (int)c->gmask2 : 0, cheb_max_);                                                                  \
+               eta_, tg_ ? (int)c->gmask2 : 0, so_);                                                                  \
     } while (0)
 
 // One implicit time level for the whole batch (F2:323-427).  On entry the old level is
@@ -921,7 +924,9 @@ static int newton_level(vch2d_ctx *c, double dt, const double *un, const double 
     const int cheb_max_ = (in_march && spectral && c->cheb_on && eta_ > 0.0) ? c->cheb_max : -1;
     // VCH_FUSED=2: fused evaluation kernels, but the `fin` step as its own launch (no hand-off inside the launch)
     const bool fin_inside = c->fused_mode == 1;
-    const EvalFin efin_{fin_inside ? c->fin_counter : (unsigned *)nullptr, c->hist_dev, c->P.kappa, c->lin_tol, eta_, cheb_max_};
+    // CG-form solves whose diagonal spans more than cg_scale_ratio run on the right-scaled system (cg_weight, vch_kernels2d.h)
+    const SolveOpts so_{cheb_max_, spectral ? c->cg_scale_ratio : 0.0};
+    const EvalFin efin_{fin_inside ? c->fin_counter : (unsigned *)nullptr, c->hist_dev, c->P.kappa, c->lin_tol, eta_, so_};
     // starting guesses (marches on the stencil-free path only; forward_core fills the coefficient tables): of the first
     // solve here, of the second solve inside the residual trial of slot 0
     const bool guess = in_march && c->guess_on && c->gmask1 != 0;
@@ -935,7 +940,7 @@ static int newton_level(vch2d_ctx *c, double dt, const double *un, const double 
                 c->x0g, efin_);
         if (!fin_inside)
             LAUNCH((k_fin_residual<2>), dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->hist_dev, c->P.kappa, dt, c->lin_tol, eta_,
-                   guess ? (int)c->gmask1 : 0, cheb_max_);
+                   guess ? (int)c->gmask1 : 0, so_);
     } else {
         LAUNCH(k_prepare, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s, c->w, un, unp1, u_stride,
                wnew_in, dt, c->wnew, c->mu0, c->cphi, c->cmu);
@@ -945,7 +950,7 @@ static int newton_level(vch2d_ctx *c, double dt, const double *un, const double 
             LAUNCHC(PC_GUESS, k_guess, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->gtab1, (const double *)c->D_s, dt, c->rhs_s,
                    c->x0g, c->part, 0);
         LAUNCH((k_fin_residual<0>), dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->hist_dev, c->P.kappa, dt, c->lin_tol, eta_,
-               guess ? (int)c->gmask1 : 0, cheb_max_);
+               guess ? (int)c->gmask1 : 0, so_);
     }
     if (c->spec) {
         for (int s = 0; s < c->spec_slots; ++s) {
@@ -976,10 +981,11 @@ static int newton_level(vch2d_ctx *c, double dt, const double *un, const double 
     if (c->debug_guess) {
         const TrajState &S = c->st_host[0];
         fprintf(stderr, "guess order %d / %d (run %d) | traj 0: ratio %.3e / %.3e solves %d sweeps %d %d %d normR %.3e active %d "
-                "tol %.3e %.3e %.3e kT %.6f %.6f %.6f form %d %d %d\n",
+                "tol %.3e %.3e %.3e kT %.6f %.6f %.6f form %d %d %d | norms %d total sweeps %ld newton %ld trials %d lastform %d lastn %d\n",
                 c->used1[0], c->used2[0], c->run2[0], S.guess_ratio, S.guess_ratio2, S.step_solves, S.step_lin[0],
                 S.step_lin[1], S.step_lin[2], S.normR, S.newton_active, S.step_tol[0], S.step_tol[1], S.step_tol[2],
-                S.step_kT[0], S.step_kT[1], S.step_kT[2], S.step_form[0], S.step_form[1], S.step_form[2]);
+                S.step_kT[0], S.step_kT[1], S.step_kT[2], S.step_form[0], S.step_form[1], S.step_form[2], S.iters, S.lin_total,
+                S.newton_total, S.ntrials, S.use_cheb, S.cheb_n);
     }
     int guard = 0;
     while (any_active()) {

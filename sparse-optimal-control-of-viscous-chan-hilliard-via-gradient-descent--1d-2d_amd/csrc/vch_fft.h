@@ -56,9 +56,12 @@ __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
 // reciprocal of pa*pb refined by two Newton steps, then 1/pa = r pb, 1/pb = r pa (within 2 ulp of the divisions).
 struct SpecArgs;
 template <class SP>
-__device__ __forceinline__ void spec_mult2(const SP &sp, double c1, double scale, double ma, double mb, double &fa, double &fb) {
+__device__ __forceinline__ void spec_mult2(const SP &sp, double c1, double scale, double ma, double mb, double &fa, double &fb,
+                                           int mode) {
     const double pa = sp.c0 + ma * (c1 + sp.c2 * ma), pb = sp.c0 + mb * (c1 + sp.c2 * mb);
-    const double na = scale * (sp.mult_m ? ma : 1.0), nb = scale * (sp.mult_m ? mb : 1.0);
+    // numerator: 1 (inverse of P), m (M P^-1), or mode 2 = -(c0 + c2 m^2) (the multiplier -E of the right-scaled CG form)
+    const double na = scale * (mode == 2 ? -(sp.c0 + sp.c2 * ma * ma) : (mode ? ma : 1.0));
+    const double nb = scale * (mode == 2 ? -(sp.c0 + sp.c2 * mb * mb) : (mode ? mb : 1.0));
 #if FFT_RCP
     const double d = pa * pb;
     double r = __builtin_amdgcn_rcp(d);
@@ -493,8 +496,10 @@ __global__ __launch_bounds__((FftThreads<C, LOGL>::T)) void k_dct_rows(Geom G, F
     FFT_STAMP(1);
     double dot = 0.0, dot2 = 0.0, dbar = 0.0;
     const double *Dp = nullptr, *Ob = nullptr;
+    int scaled = 0;
     if (EPI >= 3) {
         dbar = st[b].dbar;
+        scaled = (EPI != 5) ? st[b].scaled : 0;
         Dp = sp.Dslot + st[b].slot * sp.d_slot_stride + b * G.plane;
         Ob = sp.other ? sp.other + b * G.plane : nullptr;
     }
@@ -514,7 +519,7 @@ __global__ __launch_bounds__((FftThreads<C, LOGL>::T)) void k_dct_rows(Geom G, F
         }
         ob[o] = v;
         if (EPI >= 3) {
-            const double wd = wdev(row, k, G) * (Dp[o] - dbar);
+            const double wd = wdev(row, k, G) * cg_weight(Dp[o], dbar, scaled);
             dot += wd * ((Ob ? Ob[o] : v) * v);
             dot2 += wd * (v * v);
         }
@@ -674,6 +679,16 @@ __global__ __launch_bounds__(NTH) void k_dmu_ceiling_fin(Geom G, Phys P, TrajSta
     }
     if (alpha != 0.0) load_tile_axpy<1>(sx, x + pb, f.p_last + pb, alpha, G, c0, r0);
     else load_tile<1>(sx, x + pb, G, c0, r0);
+    if (st[b].scaled) {                   // right-scaled CG form: the iterate was y, dphi = (dbar / D) y (halo included)
+        __syncthreads();
+        const double dbar = st[b].dbar;
+        const double *Dp = D_s + slot * slot_stride + pb;
+        for (int e = threadIdx.x; e < W * (TY + 2); e += NTH) {
+            int ly = e / W, lxx = e - ly * W;
+            int gr = refl(r0 - 1 + ly, G.ns), gc = refl(c0 - 1 + lxx, G.nf);
+            sx[e] *= dbar / Dp[(long)gr * G.pitch + gc];
+        }
+    }
     __syncthreads();
     double acc[1] = {1e300};
     for (int k = 0; k < TY / 4; ++k) {
@@ -762,6 +777,7 @@ __global__ __launch_bounds__((FftThreads<C, LOGL>::T)) void k_cg_rows_fwd(Geom G
         }
     }
     const double dbar = st[b].dbar;
+    const int scaled = st[b].scaled;
     const double *Dp = a.Dslot + st[b].slot * a.d_slot_stride + pb;
     const bool primed = FIRST && a.x0 && st[b].x_primed;
     double acc = 0.0;
@@ -769,12 +785,13 @@ __global__ __launch_bounds__((FftThreads<C, LOGL>::T)) void k_cg_rows_fwd(Geom G
     auto node = [&](int row, int m, bool owner) -> double {
         if (row >= G.ns) return 0.0;
         const long o = (long)row * G.pitch + m;
-        const double dl = Dp[o] - dbar;
+        const double dl = cg_weight(Dp[o], dbar, scaled);
         double pn;
         if (FIRST) {
             pn = a.z[pb + o];
             if (owner) {
-                a.x[pb + o] = primed ? a.x0[pb + o] : 0.0;
+                // the iterate lives in y = S^-1 x on the right-scaled system: the starting guess x0 becomes (D / dbar) x0
+                a.x[pb + o] = primed ? (scaled ? a.x0[pb + o] * (Dp[o] / dbar) : a.x0[pb + o]) : 0.0;
                 a.p_new[pb + o] = pn;
             }
         } else {
@@ -1454,6 +1471,7 @@ __global__ __launch_bounds__((FftThreads<C, LOGL>::T)) void k_dct_cols(Geom G, F
         }
     };
     const double c1 = sp.c1a + sp.c1b * st[b].dbar;
+    const int mmode = (sp.mult_m && st[b].scaled) ? 2 : sp.mult_m;      // right-scaled CG form of this trajectory's solve
     double *ob = out + b * G.plane;
     // forward transform; with a compile-time plan its last pass writes the outputs back already multiplied by the
     // spectral multiplier (FFT_COLS_EMIT & 1), otherwise a separate pass over the image does
@@ -1462,14 +1480,14 @@ __global__ __launch_bounds__((FftThreads<C, LOGL>::T)) void k_dct_cols(Geom G, F
         double2 *buf_;
         const SpecArgs &sp_;
         double c1_, scale_;
-        int col0_, nf_;
+        int col0_, nf_, mode_;
         __device__ __forceinline__ void operator()(int idx, double2 v) const {
             const int f = idx >> LG, k = idx & (LL - 1), ks = k <= LL / 2 ? k : LL - k;
             const int ca = col0_ + 2 * f, cb = ca + 1;
             const double msk = sp_.ms[ks];
             const double ma = msk + sp_.mf[ca < nf_ ? ca : nf_ - 1], mb = msk + sp_.mf[cb < nf_ ? cb : nf_ - 1];
             double fa, fb;
-            spec_mult2(sp_, c1_, scale_, ma, mb, fa, fb);
+            spec_mult2(sp_, c1_, scale_, ma, mb, fa, fb, mode_);
             v.x *= fa;
             v.y *= fb;
             buf_[swz<LOGL>(idx)] = v;
@@ -1489,16 +1507,16 @@ __global__ __launch_bounds__((FftThreads<C, LOGL>::T)) void k_dct_cols(Geom G, F
             const int k = j + s * (LL >> 3), ks = k <= LL / 2 ? k : LL - k;
             const double msk = sp.ms[ks];
             double fa, fb;
-            spec_mult2(sp, c1, scale, msk + mfa, msk + mfb, fa, fb);
+            spec_mult2(sp, c1, scale, msk + mfa, msk + mfb, fa, fb, mmode);
             xr[s].x *= fa;
             xr[s].y *= fb;
         }
         fft_lds<C, LOGL, FftNoEmit, FftNoIngest, 2>(buf, ax, FftNoEmit(), FftNoIngest(), xr);
     } else if (DIRECT && (FFT_COLS_EMIT & 1)) {
         if (FFT_COLS_INGEST)
-            fft_lds<C, LOGL>(buf, ax, ScaleEmit{buf, sp, c1, scale, col0, G.nf}, ColIngest{ib, (long)G.pitch, col0, G.nf});
+            fft_lds<C, LOGL>(buf, ax, ScaleEmit{buf, sp, c1, scale, col0, G.nf, mmode}, ColIngest{ib, (long)G.pitch, col0, G.nf});
         else
-            fft_lds<C, LOGL>(buf, ax, ScaleEmit{buf, sp, c1, scale, col0, G.nf});
+            fft_lds<C, LOGL>(buf, ax, ScaleEmit{buf, sp, c1, scale, col0, G.nf, mmode});
     } else {
         fft_lds<C, LOGL>(buf, ax);
         for (int idx = tid; idx < nfft * L; idx += T) {
@@ -1509,7 +1527,7 @@ __global__ __launch_bounds__((FftThreads<C, LOGL>::T)) void k_dct_cols(Geom G, F
             double2 v = buf[swz<LOGL>(idx)];
             double ma = msk + sp.mf[ca < G.nf ? ca : G.nf - 1], mb = msk + sp.mf[cb < G.nf ? cb : G.nf - 1];
             double fa, fb;
-            spec_mult2(sp, c1, scale, ma, mb, fa, fb);
+            spec_mult2(sp, c1, scale, ma, mb, fa, fb, mmode);
             v.x *= fa;
             v.y *= fb;
             buf[swz<LOGL>(idx)] = v;

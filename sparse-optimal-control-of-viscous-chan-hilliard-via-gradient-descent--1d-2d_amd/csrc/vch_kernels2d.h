@@ -64,6 +64,9 @@ struct TrajState {
                                // solve on the device, so a trajectory's arithmetic does not depend on its batch mates
     double cheb_theta, cheb_delta;
     int step_form[4];          // use_cheb of the step's first four solves (host: which launch sequences the next step needs)
+    // CG form on a diagonal that spans a wide range (a few nodes near |phi| = 1 among ordinary ones): the solve runs on the
+    // right-scaled system  P^-1 A S y = P^-1 rhs,  x = S y,  S = dbar / D  (see cg_scaled below)
+    int scaled, scaled_pad;
     int lin_took, lin_unconv;  // adjoint: this solve started (its y is valid); solves the enqueued sweeps did not finish
     int cg_pending, cg_pbuf, cg_pad;   // forward CG: step (alpha, p[cg_pbuf]) computed but not yet added to x
     // forward CG, per-iteration state in two copies: iteration k's stencil kernel derives the step of
@@ -269,6 +272,7 @@ __device__ __forceinline__ void newton_begin(TrajState &S) {
     S.step_chn[0] = S.step_chn[1] = S.step_chn[2] = S.step_chn[3] = 0;
     S.step_form[0] = S.step_form[1] = S.step_form[2] = S.step_form[3] = 0;
     S.use_cheb = 0;
+    S.scaled = 0;
     S.x_primed = 0;
     S.lin_rscale = 1.0;
     S.guess_ratio = 1.0;
@@ -1134,6 +1138,26 @@ __device__ __forceinline__ double newton_lin_tol(double r0, double lin_tol, doub
     return fmin(fmax(lin_tol, eta / r0), 0.5);
 }
 
+// Options of the forward solves of a march, passed to the fin kernels that set a solve up.
+struct SolveOpts {
+    int cheb_max;              // plans of at most that many sweeps take the reduction-free form (-1: never, the CG form always)
+    double scale_ratio;        // CG form: Dmax > scale_ratio * Dmin switches to the right-scaled system (0: never)
+};
+
+// Right-scaled CG form.  With S = dbar / D (a diagonal in (0, 1]) the Schur operator is
+//     A S = (I/dt + kappa/2 M^2)(I - F) + dbar M (I - F) + M D S ... = P - (I/dt + kappa/2 M^2) F,     F = I - S = (D - dbar) / D,
+// so  T = P^-1 A S = I - E F  with the spectral multiplier  E = (I/dt + kappa/2 M^2) P^-1  in (0, 1).  T is self-adjoint and
+// positive in <x, y>_F = sum W F x y, spectrum in [dbar / Dmax, 1]: the same worst-case bound as the unscaled form, but a node
+// whose D is a hundred times its neighbours' -- |phi| within 1e-2 of 1, F ~ 1 -- now contributes an eigenvalue near
+// 1 - mean(E) ~ 0.3-0.5 instead of 1 + (D - dbar) mean(M P^-1) ~ 50, and CG, which adapts to the spectrum it meets, needs a
+// tenth of the sweeps on the clipped-noise start of BASELINE config 5 (profiles/r03_config5.txt).
+// In kernel terms, against the unscaled form  q = p + (M P^-1)((D - dbar) p):  weight (D - dbar) / D instead of D - dbar,
+// multiplier -(1/dt + kappa/2 m^2) / P(m) instead of m / P(m), and x = (dbar / D) y at the end.
+__device__ __forceinline__ double cg_weight(double D, double dbar, int scaled) {
+    const double dl = D - dbar;
+    return scaled ? dl / D : dl;
+}
+
 // Chebyshev plan of a forward solve: with spec(P^-1 A) in [1, kT] (cg_setup) the iteration
 //     y_1 = b~ / theta,   y_{j+1} = y_j + rho_j rho_{j-1} (y_j - y_{j-1}) + (2 rho_j / delta) (b~ - P^-1 A y_j)
 // (b~ = P^-1 rhs, rho_0 = delta / theta, rho_j = 1 / (2 theta / delta - rho_{j-1})) leaves, in the norm the stop test of the
@@ -1173,12 +1197,12 @@ __device__ __forceinline__ double cheb_last_factor(double theta, double delta, i
 
 template <int MODE>
 __device__ __forceinline__ void fin_residual_update(TrajState &S, const double (&v)[NPART], bool primed, double *__restrict__ hist,
-                                                    double kappa, double dt, double lin_tol, double eta, int cheb_max);
+                                                    double kappa, double dt, double lin_tol, double eta, SolveOpts so);
 
 template <int MODE>
 __global__ void k_fin_residual(TrajState *st, const double *__restrict__ part, int nblk,
                                double *__restrict__ hist, double kappa, double dt, double lin_tol, double eta, int guess,
-                               int cheb_max) {
+                               SolveOpts so) {
     const int b = blockIdx.x;
     // the record is worked on in registers and written back once: through a reference every field access is a global
     // memory round trip and the state machine below a chain of them (one workgroup, nothing to hide them behind)
@@ -1196,14 +1220,13 @@ __global__ void k_fin_residual(TrajState *st, const double *__restrict__ part, i
     const bool primed = guess_bit((unsigned)guess, b) && (MODE != 1 || S.iters == 1);
     fin_reduce(part, nblk, b, v, op, primed ? 5 : 4);
     if (threadIdx.x != 0) return;
-    fin_residual_update<(MODE == 1 ? 1 : 0)>(S, v, primed, hist + (long)b * HIST_CAP, kappa, dt, lin_tol, eta, cheb_max);
+    fin_residual_update<(MODE == 1 ? 1 : 0)>(S, v, primed, hist + (long)b * HIST_CAP, kappa, dt, lin_tol, eta, so);
     st[b] = S;
 }
 
-// cheb_max: plans of at most that many sweeps take the reduction-free form (-1: never, the CG form always)
 template <int MODE>
 __device__ __forceinline__ void fin_residual_update(TrajState &S, const double (&v)[NPART], bool primed, double *__restrict__ hist,
-                                                    double kappa, double dt, double lin_tol, double eta, int cheb_max) {
+                                                    double kappa, double dt, double lin_tol, double eta, SolveOpts so) {
     const double nt = sqrt(v[0]);
     bool accept;
     if (MODE == 0) {
@@ -1243,7 +1266,8 @@ __device__ __forceinline__ void fin_residual_update(TrajState &S, const double (
         S.lin_reltol = newton_lin_tol(S.lin_r0, lin_tol, eta);
         cg_setup(S, 2.0 * sqrt(0.5 * kappa / dt), 1.0, S.lin_reltol);
         cheb_plan(S, S.lin_reltol);
-        S.use_cheb = (cheb_max >= 0 && S.cheb_n <= cheb_max) ? 1 : 0;
+        S.use_cheb = (so.cheb_max >= 0 && S.cheb_n <= so.cheb_max) ? 1 : 0;
+        S.scaled = (!S.use_cheb && so.scale_ratio > 0.0 && S.Dmax > so.scale_ratio * S.Dmin) ? 1 : 0;
         S.lin_active = 1;
         S.lin_it = 0;
         S.lin_prev = 1e300;
@@ -1296,7 +1320,7 @@ struct EvalFin {
     unsigned *counter;         // [B], zero between launches
     double *hist;              // [B][HIST_CAP] residual-norm histories
     double kappa, lin_tol, eta;
-    int cheb_max;
+    SolveOpts so;
 };
 
 __device__ __forceinline__ void store_agent(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -1571,7 +1595,7 @@ __global__ __launch_bounds__(NTH, EVAL_MINBLK) void k_eval(Geom G, Phys P, TrajS
             S.slot = dst;                         // the evaluated start iterate lives there (a trial flips the slot when accepted)
         }
         fin_residual_update<(MODE == 0 ? 0 : 1)>(S, v, do_guess, fin.hist + (long)b * HIST_CAP, fin.kappa, dt, fin.lin_tol, fin.eta,
-                                                 fin.cheb_max);
+                                                 fin.so);
         st[b] = S;
     }
 }
@@ -1868,6 +1892,7 @@ __global__ void k_fin_lin_begin(TrajState *st, const double *__restrict__ part, 
     S.lin_rel = 1.0;
     S.lin_reltol = lin_tol;
     S.use_cheb = 0;
+    S.scaled = 0;
     S.nsolves++;
 }
 

@@ -301,6 +301,46 @@ def test_stress_128_vs_reference(V, O2):
         phi = ph[k + 1]
 
 
+def _stress_vs_reference(V, O2, name, sub):
+    g = golden(name)
+    N, M, dt = int(g["N"]), int(g["M"]), float(g["dt"])
+    e = V.Engine2D(Nx=N, Ny=N, max_steps=M)
+    phi = O2.init_phi_random(N, N, 1e-2, amp=1.0, seed=42)
+    assert abs(np.mean(np.abs(phi) >= 0.99) - float(g["clipped_frac0"])) < 1e-12
+    ph, st = e.forward(phi, np.full(M, dt))
+    assert relerr(ph[:, ::sub, ::sub], g["phi_sub"]) < SOLVE, st
+    assert np.allclose(np.sqrt((ph.reshape(M + 1, -1) ** 2).sum(axis=1)), g["nrm_phi"], rtol=1e-9)
+    assert st["newton_iters"] == int(g["n_hist"].sum()), (st, g["n_hist"])
+    # the reference evaluates the residual at the top of every loop pass (= one norm recorded) and once per Armijo trial
+    assert st["newton_iters"] + st["armijo_trials"] == int(g["res_evals"].sum()), (st, g["res_evals"])
+    w = np.zeros_like(phi)
+    mu = e.initialize_mu(phi, w)
+    for k in range(M):
+        phi, mu, hist, s1 = e.newton_raphson(phi, mu, w, w, dt)
+        ref = g["hists"][k, :int(g["n_hist"][k])]
+        assert len(hist) == len(ref), (k, hist, ref)
+        big = ref > 1e-6                              # below that the norm is evaluation round-off (|L mu| eps grows with N^2)
+        assert np.allclose(np.asarray(hist)[big], ref[big], rtol=1e-5), (k, hist, ref)
+        assert hist[-1] < 1e-6
+        assert s1["newton_iters"] + s1["armijo_trials"] == int(g["res_evals"][k]), (k, s1, g["res_evals"])
+        phi = ph[k + 1]
+    e.close()
+
+
+def test_stress_256_vs_reference(V, O2):
+    """The near-singular start (amp = 1.0, a third of the nodes clipped) at 256^2, dt = 1e-3, 3 steps, against the
+    reference's own run (tests/golden/make_golden_r3.py): Newton histories of every call (same length, same values above
+    the evaluation floor), residual evaluations per step (step ceiling / Armijo path F2:377-423) and the fields."""
+    _stress_vs_reference(V, O2, "g2d_stress_256.npz", 4)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g2d_stress_1024.npz")),
+                    reason="the 1024^2 reference golden takes hours of SuperLU time to make (make_golden_r3.py --only stress1024)")
+def test_stress_1024_vs_reference(V, O2):
+    """BASELINE config 5's own grid: the first two steps at 1024^2 against the reference's run."""
+    _stress_vs_reference(V, O2, "g2d_stress_1024.npz", 16)
+
+
 def test_config5_stress_march_1024(V, O2):
     """BASELINE config 5 at size: 1024^2, amp = 1.0, dt = 1e-3, 100 steps, one trajectory: the reference's Newton
     exit semantics (history <= 500 per call, <= 12 Armijo halvings per iteration, F2:394-423), mass conservation,
@@ -319,9 +359,33 @@ def test_config5_stress_march_1024(V, O2):
     lv = list(range(0, M + 1, 10))
     mass = np.array([np.sum(wts * ph[k]) for k in lv])
     assert np.abs(mass - mass[0]).max() <= 1e-10 * wts.sum()
-    assert M < st["newton_iters"] <= 500 * M
     iters = st["newton_iters"] - M                                  # Newton iterations = norms recorded after the first
     assert st["armijo_trials"] <= 12 * max(iters, 1) + M and st["linear_solves"] <= iters + M, st
+    # measured ceiling of the regime (this march: ~15 norms and ~30 trials per step; the reference itself takes 5 norms and
+    # 9 residual evaluations in the first step at 256^2, make_golden_r3.py): far below the loop limits of F2:353,398
+    assert M < st["newton_iters"] <= 40 * M and st["armijo_trials"] <= 80 * M, st
+    # is that count the physics or the inexact solves?  The same march (its first 25 steps, the hardest: the second step alone
+    # runs ~250 damped Newton iterations on a state with |phi| = 0.99 at 0.5 % of the nodes, and from the third step on the
+    # iteration ends at the residual's evaluation floor through the no-progress exit of F2:420-425) with every solve driven to
+    # round-off (VCH_LIN_ETA=0: the forcing rule off) takes the same Newton iterations, solves and trials to within 10 % --
+    # not exactly: with hundreds of damped iterations a trial that passes the Armijo test by 1e-9 on one path fails it on the
+    # other, as it would between two direct solvers -- and gives the same fields
+    import os as _os
+    M2 = 25
+    e_a = V.Engine2D(Nx=N, Ny=N, batch=1, max_steps=M2)
+    ph_a, st_a = e_a.forward(phi0, dts[:M2])
+    e_a.close()
+    _os.environ["VCH_LIN_ETA"] = "0"
+    try:
+        e_b = V.Engine2D(Nx=N, Ny=N, batch=1, max_steps=M2)
+        ph_b, st_b = e_b.forward(phi0, dts[:M2])
+        e_b.close()
+    finally:
+        del _os.environ["VCH_LIN_ETA"]
+    cnt = lambda q: (q["newton_iters"], q["linear_solves"], q["armijo_trials"])
+    assert all(abs(x - y) <= 0.10 * y for x, y in zip(cnt(st_a), cnt(st_b))), (st_a, st_b)
+    assert np.array_equal(ph_a, ph[:M2 + 1])
+    assert np.max(np.abs(ph_a - ph_b)) < 1e-6, float(np.max(np.abs(ph_a - ph_b)))
     E = e.free_energy_resident(M + 1)
     assert E[-1] < E[0]
     # true residuals on the near-singular final state
