@@ -28,9 +28,14 @@ class VchError(RuntimeError):
 HASH_PATH = LIB_PATH + ".srchash"
 
 
-def source_hash() -> str:
-    """sha256 over the contents of every file the shared library is built from (names included)."""
+BUILD_FLAGS = ["-O3", "--offload-arch=gfx950", "-shared", "-fPIC", "-std=c++17", "-Wno-unused-value", "-Wno-unused-result"]
+
+
+def source_hash(defines=()) -> str:
+    """sha256 over the contents of every file the shared library is built from (names included), the compiler flags and
+    the -D defines of the build: a tuning build (A/B defines) never passes for the default one."""
     h = hashlib.sha256()
+    h.update(" ".join(BUILD_FLAGS + sorted(f"-D{d}" for d in defines)).encode())
     for d in DEPS:
         p = d if os.path.isabs(d) else os.path.join(CSRC, d)
         h.update(os.path.basename(p).encode())
@@ -55,9 +60,8 @@ def build(force: bool = False, verbose: bool = False, defines=(), out=None) -> s
         return LIB_PATH                      # an explicitly selected prebuilt variant
     if out is None and not force and not _stale():
         return LIB_PATH
-    cmd = [HIPCC, "-O3", "--offload-arch=gfx950", "-shared", "-fPIC", "-std=c++17",
-           "-Wno-unused-value", "-Wno-unused-result", "-I", CSRC,
-           "-o", out or LIB_PATH] + [f"-D{d}" for d in defines] + [os.path.join(CSRC, s) for s in SOURCES]
+    cmd = [HIPCC] + BUILD_FLAGS + ["-I", CSRC, "-o", out or LIB_PATH] + [f"-D{d}" for d in defines] + \
+          [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -65,7 +69,7 @@ def build(force: bool = False, verbose: bool = False, defines=(), out=None) -> s
         raise VchError("hipcc failed:\n" + r.stdout + r.stderr)
     if out is None:
         with open(HASH_PATH, "w") as fh:
-            fh.write(source_hash() + "\n")
+            fh.write(source_hash(defines) + "\n")      # with defines: differs from source_hash(), so the next default build() rebuilds
     return out or LIB_PATH
 
 

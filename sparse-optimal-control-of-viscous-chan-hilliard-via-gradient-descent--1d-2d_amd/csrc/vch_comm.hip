@@ -10,7 +10,21 @@
 // (vch_comm_unique_id) and handed to the other ranks by the caller over whatever channel it already has
 // (bench.py: torch.distributed broadcast_object_list) -- the engine does no networking of its own.
 #include <dlfcn.h>
-#include <rccl/rccl.h>
+
+// The few RCCL declarations the collective needs, stated here (they are part of NCCL's stable C ABI): the library is only
+// ever dlopen'ed, so building the engine must not need the RCCL headers either.
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+typedef enum { ncclDouble = 8 } ncclDataType_t;        // ncclFloat64
+}
+
+static const char *dl_why() {
+    const char *e = dlerror();
+    return e ? e : "unknown dlopen/dlsym failure";
+}
 
 struct vch_comm {
     int device, rank, world;
@@ -34,7 +48,7 @@ static void *rccl_open() {
 extern "C" int vch_comm_unique_id(unsigned char *id_out) {
     if (!id_out) return vch_fail(VCH_ERR_ARG, "vch_comm_unique_id: NULL output");
     void *h = rccl_open();
-    if (!h) return vch_fail(VCH_ERR_STATE, "vch_comm_unique_id: librccl.so.1 not loadable: %s", dlerror());
+    if (!h) return vch_fail(VCH_ERR_STATE, "vch_comm_unique_id: librccl.so.1 not loadable: %s", dl_why());
     auto get = (ncclResult_t(*)(ncclUniqueId *))dlsym(h, "ncclGetUniqueId");
     auto err = (const char *(*)(ncclResult_t))dlsym(h, "ncclGetErrorString");
     if (!get || !err) return vch_fail(VCH_ERR_STATE, "vch_comm_unique_id: RCCL symbols missing");
@@ -69,7 +83,7 @@ extern "C" vch_comm *vch_comm_create(const unsigned char *id, int rank, int worl
         delete m;
         return (vch_comm *)nullptr;
     };
-    if (!m->dl) return fail("dlopen librccl.so.1", dlerror());
+    if (!m->dl) return fail("dlopen librccl.so.1", dl_why());
     auto init = (ncclResult_t(*)(ncclComm_t *, int, ncclUniqueId, int))dlsym(m->dl, "ncclCommInitRank");
     m->AllReduce = (decltype(m->AllReduce))dlsym(m->dl, "ncclAllReduce");
     m->CommDestroy = (decltype(m->CommDestroy))dlsym(m->dl, "ncclCommDestroy");
@@ -109,23 +123,31 @@ __global__ void k_sum_costs(const double *__restrict__ J, int B, double *__restr
 
 extern "C" int vch_comm_allreduce_cost(vch_comm *m, vch2d_ctx *const *ctxs, int nctx, long iteration, double *J_sum_out) {
     if (!m || !ctxs || nctx < 1 || !J_sum_out) return vch_fail(VCH_ERR_ARG, "vch_comm_allreduce_cost: NULL argument");
-    HIPCHK(hipSetDevice(m->device));
-    HIPCHK(hipMemsetAsync(m->sum_dev, 0, 5 * sizeof(double), m->stream));
+    // every argument is checked BEFORE anything is enqueued: a rank that returns an error here has started nothing, and
+    // its peers are not left inside a collective this rank never joins (the caller ends the job, bench.py main)
+    std::vector<const double *> src(nctx);
     for (int i = 0; i < nctx; ++i) {
         vch2d_ctx *c = ctxs[i];
         if (!c || !c->pgd_ready) return vch_fail(VCH_ERR_STATE, "vch_comm_allreduce_cost: context %d has no PGD problem loaded", i);
         if (c->device != m->device) return vch_fail(VCH_ERR_ARG, "vch_comm_allreduce_cost: context %d lives on another device", i);
+        src[i] = c->J_dev;                               // iteration < 0: the current iterate
+        if (iteration >= 0) {
+            // the context's worker thread advances the counter while this (main) thread reads it
+            const long done = c->pgd_iter_total.load(std::memory_order_acquire);
+            if (iteration >= done || iteration < done - J_RING)
+                return vch_fail(VCH_ERR_STATE, "vch_comm_allreduce_cost: iteration %ld of context %d is not in the ring (%ld done)",
+                                iteration, i, done);
+            src[i] = c->J_ring_dev + (size_t)(iteration % J_RING) * 5 * c->B;
+        }
+    }
+    HIPCHK(hipSetDevice(m->device));
+    HIPCHK(hipMemsetAsync(m->sum_dev, 0, 5 * sizeof(double), m->stream));
+    for (int i = 0; i < nctx; ++i) {
+        vch2d_ctx *c = ctxs[i];
         // order after the context's own work (its J_dev upload), without blocking the host
         HIPCHK(hipEventRecord(m->ev, c->stream));
         HIPCHK(hipStreamWaitEvent(m->stream, m->ev, 0));
-        const double *src = c->J_dev;                    // iteration < 0: the current iterate
-        if (iteration >= 0) {
-            if (iteration >= c->pgd_iter_total || iteration < c->pgd_iter_total - J_RING)
-                return vch_fail(VCH_ERR_STATE, "vch_comm_allreduce_cost: iteration %ld of context %d is not in the ring (%ld done)",
-                                iteration, i, c->pgd_iter_total);
-            src = c->J_ring_dev + (size_t)(iteration % J_RING) * 5 * c->B;
-        }
-        hipLaunchKernelGGL(k_sum_costs, dim3(1), dim3(64), 0, m->stream, src, c->B, m->sum_dev);
+        hipLaunchKernelGGL(k_sum_costs, dim3(1), dim3(64), 0, m->stream, src[i], c->B, m->sum_dev);
         HIPCHK(hipGetLastError());
     }
     ncclResult_t r = m->AllReduce(m->sum_dev, m->sum_dev, 5, ncclDouble, ncclSum, m->comm, m->stream);

@@ -8,6 +8,7 @@
 #include "vch_gemm.h"
 #include "vch_fft.h"
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 
@@ -181,7 +182,7 @@ struct vch2d_ctx {
     // that the collective of iteration k (vch_comm_allreduce_cost) reads iteration k's values even when the context
     // has already gone on; J_ring_host is the pinned staging copy
     double *J_ring_dev, *J_ring_host;
-    long pgd_iter_total;                  // iterations performed since vch2d_pgd_init
+    std::atomic<long> pgd_iter_total;     // iterations performed since vch2d_pgd_init (read by the collective's thread)
     long tot_launch, tot_sync;            // launches / looks accumulated over the context's life (vch2d_counters)
     // per-kernel-class HIP-event timing (bench.py roofline leg)
     bool prof_on;
@@ -2157,10 +2158,10 @@ extern "C" int vch2d_pgd_iterate(vch2d_ctx *c, int n_iters, double *cost_out, do
         VCHCHK(reset_counters(c));
         done_iters = it + 1;
         {   // this iteration's cost scalars into the ring (read by the collective of this iteration)
-            const size_t slot = (size_t)(c->pgd_iter_total % J_RING) * 5 * B;
+            const size_t slot = (size_t)(c->pgd_iter_total.load(std::memory_order_relaxed) % J_RING) * 5 * B;
             memcpy(c->J_ring_host + slot, c->pgd_J.data(), sizeof(double) * 5 * B);
             HIPCHK(hipMemcpyAsync(c->J_ring_dev + slot, c->J_ring_host + slot, sizeof(double) * 5 * B, hipMemcpyHostToDevice, c->stream));
-            c->pgd_iter_total++;
+            c->pgd_iter_total.fetch_add(1, std::memory_order_release);
         }
     }
     HIPCHK(hipMemcpyAsync(c->J_dev, c->pgd_J.data(), sizeof(double) * 5 * B, hipMemcpyHostToDevice, c->stream));

@@ -55,7 +55,7 @@ def test_struct_layouts_match_header():
     L = __import__("importlib").import_module(vch_amd.PKG_NAME + "._lib")
     assert ctypes.sizeof(L.Params2D) == 2 * 4 + 7 * 8
     assert ctypes.sizeof(L.OptParams) == 5 * 8 + 8 + 2 * 8      # int32 + padding before u_min
-    assert ctypes.sizeof(L.Stats) == 9 * 8
+    assert ctypes.sizeof(L.Stats) == 10 * 8           # ABI version 3: + unconverged_solves
 
 
 def test_time_grid_rule(V):
