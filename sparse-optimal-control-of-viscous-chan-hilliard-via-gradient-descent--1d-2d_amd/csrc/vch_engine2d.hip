@@ -961,10 +961,8 @@ static int newton_level(vch2d_ctx *c, double dt, const double *un, const double 
             if (cheb_max_ < 0 || (c->spec_form[s] & 2)) VCHCHK(schur_solve(c, dt, c->spec_cgb[s], false));
             VCHCHK(dmu_ceiling(c, 1));
             // the second solve's guess goes with the trial that follows a trajectory's FIRST solve (the kernels check
-            // iters == 1), in whichever slot that solve finished: the result must not depend on the launch schedule.  Only
-            // the separate-kernel form (VCH_FUSED=0) saves the k_guess launches of the later slots and starts such late
-            // second solves from zero.
-            const bool trial_guess_ = fused || s == 0;
+            // iters == 1), in whichever slot that solve finished: the result must not depend on the launch schedule
+            const bool trial_guess_ = true;
             RESIDUAL_TRIAL();
         }
     }
