@@ -920,8 +920,11 @@ struct ChebSweepArgs {
 };
 
 // FIRST = 1: the kernel with j = 0 (a separate instantiation: its branches fold, and profiles tell the two apart)
+#ifndef CHEB_MINW
+#define CHEB_MINW 1            // minimum waves per SIMD the register allocation of k_cheb_rows must allow (A/B knob)
+#endif
 template <int C, int LOGL, int FIRST>
-__global__ __launch_bounds__((FftThreads<C, LOGL>::T)) void k_cheb_rows(Geom G, FftAxis ax, ChebSweepArgs a_, const double *__restrict__ in,
+__global__ __launch_bounds__((FftThreads<C, LOGL>::T), CHEB_MINW) void k_cheb_rows(Geom G, FftAxis ax, ChebSweepArgs a_, const double *__restrict__ in,
                                                                        double *__restrict__ out, const TrajState *__restrict__ st) {
     const int b = blockIdx.z;
     ChebSweepArgs a = a_;

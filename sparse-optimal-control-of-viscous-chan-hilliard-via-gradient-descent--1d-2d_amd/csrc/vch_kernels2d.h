@@ -536,7 +536,10 @@ __global__ __launch_bounds__(NTH) void k_schur(Geom G, Phys P, const TrajState *
 // ---------------------------------------------------------------------------------
 constexpr int GUESS_RING = 8;     // increments kept (a power of two)
 constexpr int GUESS_ORD = 8;      // at most this many planes enter one guess (forward: <= 6 increments; adjoint: every second level)
-constexpr int GUESS_BMAX = 32;    // trajectories per context with coefficients of their own (beyond: one common set, row 0)
+#ifndef VCH_GUESS_BMAX
+#define VCH_GUESS_BMAX 32
+#endif
+constexpr int GUESS_BMAX = VCH_GUESS_BMAX;    // trajectories per context with coefficients of their own (beyond: one common set, row 0)
 struct GuessArgs {
     const double *d[GUESS_ORD];   // first Newton increments of steps n-1 .. n-GUESS_ORD, [B][plane]
     // their coefficients (0 = plane not used), PER TRAJECTORY: the order of the extrapolation is chosen for every
