@@ -140,7 +140,11 @@ __device__ __forceinline__ double lap_at(const double *s, int p, double ax, doub
 __device__ __forceinline__ double reglog(double phi) {   // F2:86-102 with delta_sep = 1e-2
     const double eps = 0.5 * DELTA_SEP;                  // max(1e-8, delta_sep/2)
     double p = fmin(fmax(phi, -1.0 + eps), 1.0 - eps);
+#ifdef VCH_FAKE_LOG                                      // timing experiment only (wrong numbers): how much of the evaluation
+    return 2.0 * p * (1.0 + 0.33 * p * p);               // kernels' time is the logarithm and the quotient?
+#else
     return log((1.0 + p) / (1.0 - p));
+#endif
 }
 
 __device__ __forceinline__ double jac_diag(double phi, double tau_dt, double c1) {   // F2:243-244
@@ -1353,6 +1357,12 @@ __device__ __forceinline__ void fin_reduce_agent(const double *part, int nblk, i
 #ifndef EVAL_MINBLK
 #define EVAL_MINBLK 5          // workgroups per CU the register allocation must allow (LDS allows 5)
 #endif
+#ifndef EVAL_PREFETCH
+#define EVAL_PREFETCH 1        // 1: every global operand of the later phases is loaded into registers BEFORE the first barrier,
+                               // so a workgroup pays the global-memory latency once instead of once per phase (march at 8
+                               // trajectories 0.533 -> 0.517 s, bench 5.17 -> 5.31; with the register cap lifted to fit them
+                               // all, 122 VGPRs = 4 workgroups per CU: 0.551 s; profiles/r03_fused_ab.txt)
+#endif
 template <int MODE>
 __global__ __launch_bounds__(NTH, EVAL_MINBLK) void k_eval(Geom G, Phys P, TrajState *st, long slot_stride, double *phi_s, double *mu_s,
                                               double *Rphi_s, double *rhs_s, double *D_s, const double *dphi, double *cphi,
@@ -1390,8 +1400,25 @@ __global__ __launch_bounds__(NTH, EVAL_MINBLK) void k_eval(Geom G, Phys P, TrajS
     double acc[5] = {0.0, 0.0, 1e300, -1e300, 0.0};
     if (MODE == 0) {
         // ---- k_prepare + k_residual<0> ----
+        constexpr int N1 = (TY + 2) * W1, I1 = (N1 + NTH - 1) / NTH;      // halo-1 elements, per thread
         load_tile<2>(sp, phi_s + src * slot_stride + pb, G, c0, r0);
         load_tile<1>(sm, mu_s + src * slot_stride + pb, G, c0, r0);          // mu of the old level
+#if EVAL_PREFETCH
+        double vW[I1], vU0[I1], vU1[I1];
+#pragma unroll
+        for (int i = 0; i < I1; ++i) {
+            const int e = threadIdx.x + i * NTH;
+            vW[i] = vU0[i] = vU1[i] = 0.0;
+            if (e < N1) {
+                int ly = e / W1, lxx = e - ly * W1;
+                int gr = refl(r0 - 1 + ly, G.ns), gc = refl(c0 - 1 + lxx, G.nf);
+                long o = (long)gr * G.pitch + gc;
+                vW[i] = w[pb + o];
+                vU0[i] = un ? un[b * u_stride + o] : 0.0;
+                vU1[i] = unp1 ? unp1[b * u_stride + o] : 0.0;
+            }
+        }
+#endif
         __syncthreads();
         for (int k = 0; k < TY / 4; ++k) {                                   // c_mu needs the Laplacian of the old mu
             int ly = ly0 + 4 * k, r = r0 + ly, c = c0 + lx;
@@ -1405,14 +1432,21 @@ __global__ __launch_bounds__(NTH, EVAL_MINBLK) void k_eval(Geom G, Phys P, TrajS
         }
         __syncthreads();
         const double gdt = P.gamma / dt;
-        for (int e = threadIdx.x; e < (TY + 2) * W1; e += NTH) {
+#pragma unroll
+        for (int i = 0; i < I1; ++i) {
+            const int e = threadIdx.x + i * NTH;
+            if (e >= N1) continue;
             int ly = e / W1, lxx = e - ly * W1;
             int rr = r0 - 1 + ly, cc = c0 - 1 + lxx;
             int gr = refl(rr, G.ns), gc = refl(cc, G.nf);
             int p2 = (ly + 1) * W2 + lxx + 1;
             long o = (long)gr * G.pitch + gc, ob = pb + o;
+#if EVAL_PREFETCH
+            const double u0 = vU0[i], u1 = vU1[i], wo = vW[i];
+#else
             const double u0 = un ? un[b * u_stride + o] : 0.0, u1 = unp1 ? unp1[b * u_stride + o] : 0.0;
             const double wo = w[ob];
+#endif
             const double wn = ((gdt - 0.5) * wo + 0.5 * (u1 + u0)) / (gdt + 0.5);
             const double ph = sp[p2], lp = lap_at<W2>(sp, p2, G.ax, G.ay);
             const double m0 = -P.kappa * lp + (P.c1 * reglog(ph) - 2.0 * P.c2 * ph) - wn;
@@ -1449,6 +1483,50 @@ __global__ __launch_bounds__(NTH, EVAL_MINBLK) void k_eval(Geom G, Phys P, TrajS
         // ---- k_residual2 ----
         const double *phi_o = phi_s + src * slot_stride + pb, *mu_o = mu_s + src * slot_stride + pb;
         const double *D_o = D_s + src * slot_stride + pb, *R_o = Rphi_s + src * slot_stride + pb;
+        constexpr int N1 = (TY + 2) * W1, I1 = (N1 + NTH - 1) / NTH;      // halo-1 elements, per thread
+#if EVAL_PREFETCH
+        // phase-1 loads first (the compiler's vmcnt then waits for them only), the later phases' operands right behind
+        double pd[(W2 * (TY + 4) + NTH - 1) / NTH], pp[(W2 * (TY + 4) + NTH - 1) / NTH];
+        {
+            int i = 0;
+#pragma unroll
+            for (int e = threadIdx.x; e < W2 * (TY + 4); e += NTH, ++i) {
+                int ly = e / W2, lxx = e - ly * W2;
+                int gr = refl(r0 - 2 + ly, G.ns), gc = refl(c0 - 2 + lxx, G.nf);
+                long o = (long)gr * G.pitch + gc;
+                pd[i] = dphi[pb + o];
+                pp[i] = phi_o[o];
+            }
+        }
+        double vD[I1], vR[I1], vM[I1], vC[I1], vcm[TY / 4];
+#pragma unroll
+        for (int i = 0; i < I1; ++i) {
+            const int e = threadIdx.x + i * NTH;
+            vD[i] = vR[i] = vM[i] = vC[i] = 0.0;
+            if (e < N1) {
+                int ly = e / W1, lxx = e - ly * W1;
+                int gr = refl(r0 - 1 + ly, G.ns), gc = refl(c0 - 1 + lxx, G.nf);
+                long o = (long)gr * G.pitch + gc;
+                vD[i] = D_o[o];
+                vR[i] = R_o[o];
+                vM[i] = mu_o[o];
+                vC[i] = cphi[pb + o];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < TY / 4; ++k) {
+            int r = r0 + ly0 + 4 * k, c = c0 + lx;
+            vcm[k] = (r < G.ns && c < G.nf) ? cmu[pb + (long)r * G.pitch + c] : 0.0;
+        }
+        {
+            int i = 0;
+#pragma unroll
+            for (int e = threadIdx.x; e < W2 * (TY + 4); e += NTH, ++i) {
+                sd[e] = pd[i];
+                sp[e] = pp[i] + S_alpha * pd[i];
+            }
+        }
+#else
         for (int e = threadIdx.x; e < W2 * (TY + 4); e += NTH) {
             int ly = e / W2, lxx = e - ly * W2;
             int gr = refl(r0 - 2 + ly, G.ns), gc = refl(c0 - 2 + lxx, G.nf);
@@ -1457,14 +1535,24 @@ __global__ __launch_bounds__(NTH, EVAL_MINBLK) void k_eval(Geom G, Phys P, TrajS
             sd[e] = d;
             sp[e] = phi_o[o] + S_alpha * d;
         }
+#endif
         __syncthreads();
-        for (int e = threadIdx.x; e < (TY + 2) * W1; e += NTH) {
-            int ly = e / W1, lxx = e - ly * W1;
-            int gr = refl(r0 - 1 + ly, G.ns), gc = refl(c0 - 1 + lxx, G.nf);
-            int p2 = (ly + 1) * W2 + lxx + 1;
-            long o = (long)gr * G.pitch + gc;
-            const double dm = 2.0 * ((-0.5 * P.kappa * lap_at<W2>(sd, p2, G.ax, G.ay) + D_o[o] * sd[p2]) + R_o[o]);
-            sm[e] = mu_o[o] + S_alpha * dm;
+#pragma unroll
+        for (int i = 0; i < I1; ++i) {
+            const int e = threadIdx.x + i * NTH;
+            if (e < N1) {
+                int ly = e / W1, lxx = e - ly * W1;
+                int p2 = (ly + 1) * W2 + lxx + 1;
+#if EVAL_PREFETCH
+                const double Dv = vD[i], Rv = vR[i], Mv = vM[i];
+#else
+                int gr = refl(r0 - 1 + ly, G.ns), gc = refl(c0 - 1 + lxx, G.nf);
+                long o = (long)gr * G.pitch + gc;
+                const double Dv = D_o[o], Rv = R_o[o], Mv = mu_o[o];
+#endif
+                const double dm = 2.0 * ((-0.5 * P.kappa * lap_at<W2>(sd, p2, G.ax, G.ay) + Dv * sd[p2]) + Rv);
+                sm[e] = Mv + S_alpha * dm;
+            }
         }
         __syncthreads();
         double mt[TY / 4];
@@ -1473,18 +1561,31 @@ __global__ __launch_bounds__(NTH, EVAL_MINBLK) void k_eval(Geom G, Phys P, TrajS
             rm[k] = mt[k] = 0.0;
             if (r < G.ns && c < G.nf) {
                 int p1 = (ly + 1) * W1 + lx + 1, p2 = (ly + 2) * W2 + lx + 2;
-                rm[k] = sp[p2] / dt - 0.5 * lap_at<W1>(sm, p1, G.ax, G.ay) + cmu[pb + (long)r * G.pitch + c];
+#if EVAL_PREFETCH
+                const double cm = vcm[k];
+#else
+                const double cm = cmu[pb + (long)r * G.pitch + c];
+#endif
+                rm[k] = sp[p2] / dt - 0.5 * lap_at<W1>(sm, p1, G.ax, G.ay) + cm;
                 mt[k] = sm[p1];
             }
         }
         __syncthreads();
-        for (int e = threadIdx.x; e < (TY + 2) * W1; e += NTH) {
-            int ly = e / W1, lxx = e - ly * W1;
-            int gr = refl(r0 - 1 + ly, G.ns), gc = refl(c0 - 1 + lxx, G.nf);
-            int p2 = (ly + 1) * W2 + lxx + 1;
-            double ph = sp[p2];
-            sm[e] = tdt * ph - 0.5 * P.kappa * lap_at<W2>(sp, p2, G.ax, G.ay) + P.c1 * reglog(ph) - 0.5 * sm[e] +
-                    cphi[pb + (long)gr * G.pitch + gc];
+#pragma unroll
+        for (int i = 0; i < I1; ++i) {
+            const int e = threadIdx.x + i * NTH;
+            if (e < N1) {
+                int ly = e / W1, lxx = e - ly * W1;
+                int p2 = (ly + 1) * W2 + lxx + 1;
+#if EVAL_PREFETCH
+                const double cp = vC[i];
+#else
+                int gr = refl(r0 - 1 + ly, G.ns), gc = refl(c0 - 1 + lxx, G.nf);
+                const double cp = cphi[pb + (long)gr * G.pitch + gc];
+#endif
+                double ph = sp[p2];
+                sm[e] = tdt * ph - 0.5 * P.kappa * lap_at<W2>(sp, p2, G.ax, G.ay) + P.c1 * reglog(ph) - 0.5 * sm[e] + cp;
+            }
         }
         __syncthreads();
         for (int k = 0; k < TY / 4; ++k) {
