@@ -1096,6 +1096,26 @@ __device__ __forceinline__ void fin_reduce(const double *part, int nblk, int b, 
         if (k < n) out[k] = op[k] == 0 ? wave_sum(a[k]) : (op[k] == 1 ? wave_min(a[k]) : wave_max(a[k]));
 }
 
+// The fin kernels work on a trajectory's record in LDS: the 64 lanes copy it in (and out) together, one lane advances it.
+// (A per-thread copy `TrajState S = st[b]` lives in private memory -- the record has arrays indexed at run time -- and
+// costs ~120 scratch instructions and 70 one-lane global loads / stores per launch; through a reference to global memory
+// every field access is a round trip.)
+#ifndef FIN_LDS
+#define FIN_LDS 1
+#endif
+__device__ __forceinline__ void traj_copy_in(TrajState &dst, const TrajState *src) {
+    const unsigned *s = reinterpret_cast<const unsigned *>(src);
+    unsigned *d = reinterpret_cast<unsigned *>(&dst);
+    for (int i = threadIdx.x; i < (int)(sizeof(TrajState) / 4); i += 64) d[i] = s[i];
+    __syncthreads();
+}
+__device__ __forceinline__ void traj_copy_out(TrajState *dst, const TrajState &src) {
+    __syncthreads();
+    const unsigned *s = reinterpret_cast<const unsigned *>(&src);
+    unsigned *d = reinterpret_cast<unsigned *>(dst);
+    for (int i = threadIdx.x; i < (int)(sizeof(TrajState) / 4); i += 64) d[i] = s[i];
+}
+
 constexpr int HIST_CAP = 512;          // >= max_iter + 1 residual norms (F2:353)
 constexpr double NEWTON_TOL = 1e-6;    // F2:353
 constexpr int NEWTON_MAXIT = 500;      // F2:353
@@ -1211,13 +1231,16 @@ __global__ void k_fin_residual(TrajState *st, const double *__restrict__ part, i
                                double *__restrict__ hist, double kappa, double dt, double lin_tol, double eta, int guess,
                                SolveOpts so) {
     const int b = blockIdx.x;
-    // the record is worked on in registers and written back once: through a reference every field access is a global
-    // memory round trip and the state machine below a chain of them (one workgroup, nothing to hide them behind)
-    TrajState S = st[b];
+#if FIN_LDS
+    __shared__ TrajState S;
+    traj_copy_in(S, st + b);
     if (MODE == 2) {               // after k_eval<0> without the fin step inside: the record has not been armed yet
         if (S.frozen) return;
-        newton_begin(S);
-        S.slot = 1 - S.slot;
+        if (threadIdx.x == 0) {
+            newton_begin(S);
+            S.slot = 1 - S.slot;
+        }
+        __syncthreads();
     }
     if (!S.newton_active || !S.need_trial) return;
     double v[NPART];
@@ -1226,9 +1249,25 @@ __global__ void k_fin_residual(TrajState *st, const double *__restrict__ part, i
     // a trajectory whose first solve is done); slot 1 holds sum (rhs - A x0)^2, slot 4 sum rhs^2
     const bool primed = guess_bit((unsigned)guess, b) && (MODE != 1 || S.iters == 1);
     fin_reduce(part, nblk, b, v, op, primed ? 5 : 4);
+    if (threadIdx.x == 0)
+        fin_residual_update<(MODE == 1 ? 1 : 0)>(S, v, primed, hist + (long)b * HIST_CAP, kappa, dt, lin_tol, eta, so);
+    traj_copy_out(st + b, S);
+#else
+    TrajState S = st[b];
+    if (MODE == 2) {
+        if (S.frozen) return;
+        newton_begin(S);
+        S.slot = 1 - S.slot;
+    }
+    if (!S.newton_active || !S.need_trial) return;
+    double v[NPART];
+    const int op[NPART] = {0, 0, 1, 2, 0, 0};
+    const bool primed = guess_bit((unsigned)guess, b) && (MODE != 1 || S.iters == 1);
+    fin_reduce(part, nblk, b, v, op, primed ? 5 : 4);
     if (threadIdx.x != 0) return;
     fin_residual_update<(MODE == 1 ? 1 : 0)>(S, v, primed, hist + (long)b * HIST_CAP, kappa, dt, lin_tol, eta, so);
     st[b] = S;
+#endif
 }
 
 template <int MODE>
@@ -1890,34 +1929,42 @@ struct ChebFin {
 };
 __global__ void k_fin_ceiling(TrajState *st, const double *__restrict__ part, int nblk, int strict, int fin_copy, ChebFin cheb) {
     const int b = blockIdx.x;
-    TrajState S = st[b];                    // in registers, written back once (see k_fin_residual)
+#if FIN_LDS
+    __shared__ TrajState S;                 // the record in LDS, copied in and out by the whole wavefront (see k_fin_residual)
+    traj_copy_in(S, st + b);
+#else
+    TrajState S = st[b];
+#endif
     if (!S.newton_active || S.need_trial) return;
     if ((cheb.enq >= 0) != (S.use_cheb != 0)) return;      // the other form's launch sequence looks after this trajectory
-    if (cheb.enq >= 0 && S.lin_active) {
+    int lin_active = S.lin_active;          // (a value every lane keeps: the record itself is advanced by lane 0 only)
+    if (cheb.enq >= 0 && lin_active) {
         if (S.cheb_n > cheb.enq) return;    // unfinished: taken up again by the next solve slot / the host's loop
         double rel = 1.0;
         if (S.cheb_n >= 1) {
             const double g0 = fin_sum1(cheb.g0, cheb.gnblk, b, 1, 0), gn = fin_sum1(cheb.gn, cheb.gnblk, b, 1, 0);
             rel = g0 > 0.0 ? sqrt(fmax(gn, 0.0) / g0) : 0.0;
         }
-        rel *= cheb_last_factor(S.cheb_theta, S.cheb_delta, S.cheb_n);
-        S.lin_rel = rel;
-        S.lin_it = S.cheb_n;
-        S.lin_total += S.cheb_n;
-        if (rel * S.lin_rscale > S.lin_maxrel) S.lin_maxrel = rel * S.lin_rscale;
-        S.lin_maxabs = fmax(S.lin_maxabs, rel * S.lin_r0);
-        if (S.cheb_n > S.step_lin_max) S.step_lin_max = S.cheb_n;
-        if (S.step_solves >= 1 && S.step_solves <= 4) S.step_lin[S.step_solves - 1] = S.cheb_n;
-        S.lin_active = 0;
+        if (threadIdx.x == 0) {
+            rel *= cheb_last_factor(S.cheb_theta, S.cheb_delta, S.cheb_n);
+            S.lin_rel = rel;
+            S.lin_it = S.cheb_n;
+            S.lin_total += S.cheb_n;
+            if (rel * S.lin_rscale > S.lin_maxrel) S.lin_maxrel = rel * S.lin_rscale;
+            S.lin_maxabs = fmax(S.lin_maxabs, rel * S.lin_r0);
+            if (S.cheb_n > S.step_lin_max) S.step_lin_max = S.cheb_n;
+            if (S.step_solves >= 1 && S.step_solves <= 4) S.step_lin[S.step_solves - 1] = S.cheb_n;
+        }
+        lin_active = 0;
     }
-    if (fin_copy >= 0 && S.lin_active) {
-        S.lin_active = fin_copy == 0 ? S.ci_active[0] : S.ci_active[1];
-        if (strict && S.lin_active) {       // unfinished: only the flag goes back
-            if (threadIdx.x == 0) st[b].lin_active = S.lin_active;
+    if (fin_copy >= 0 && lin_active) {
+        lin_active = fin_copy == 0 ? S.ci_active[0] : S.ci_active[1];
+        if (strict && lin_active) {         // unfinished: only the flag goes back
+            if (threadIdx.x == 0) st[b].lin_active = lin_active;
             return;
         }
     }
-    if (strict && S.lin_active) return;
+    if (strict && lin_active) return;
     double v[NPART];
     const int op[NPART] = {1, 0, 0, 0, 0, 0};
     if (cheb.enq >= 0 && cheb.cmin) {
@@ -1927,21 +1974,24 @@ __global__ void k_fin_ceiling(TrajState *st, const double *__restrict__ part, in
     } else {
         fin_reduce(part, nblk, b, v, op, 1);
     }
-    if (threadIdx.x != 0) return;
-    double amax = 2.0;
-    if (v[0] < 1e299) amax = fmin(amax, 0.9 * v[0]);
-    if (!isfinite(amax) || amax <= 0.0) amax = 1.0;
-    S.alpha = fmin(1.0, amax);
-    if (S.lin_active) {          // the host's sweep budget ran out: go on with an inexact step
-        S.lin_active = 0;
-        if (S.lin_rel > S.lin_maxrel) S.lin_maxrel = S.lin_rel;
+    if (threadIdx.x == 0) {
+        double amax = 2.0;
+        if (v[0] < 1e299) amax = fmin(amax, 0.9 * v[0]);
+        if (!isfinite(amax) || amax <= 0.0) amax = 1.0;
+        S.alpha = fmin(1.0, amax);
+        if (lin_active && S.lin_rel > S.lin_maxrel) S.lin_maxrel = S.lin_rel;     // the host's sweep budget ran out: go on
+        S.lin_active = 0;                                                         // with an inexact step
+        S.need_trial = 1;
+        S.trial_no = 0;
+        S.force_accept = 0;
+        S.best_norm = 1e300;
+        S.best_alpha = S.alpha;
     }
-    S.need_trial = 1;
-    S.trial_no = 0;
-    S.force_accept = 0;
-    S.best_norm = 1e300;
-    S.best_alpha = S.alpha;
-    st[b] = S;
+#if FIN_LDS
+    traj_copy_out(st + b, S);
+#else
+    if (threadIdx.x == 0) st[b] = S;
+#endif
 }
 
 __global__ void k_fin_mass(TrajState *st, const double *__restrict__ part, int nblk, int init) {
