@@ -110,6 +110,7 @@ struct vch2d_ctx {
     int fused_mode;                       // 0 separate kernels, 1 fused with the fin step inside, 2 fused + fin launches
     unsigned *fin_counter;
     int cheb_enq, spec_chn[4], cheb_margin, cheb_max;
+    double eta1_factor;                   // first solve of a step: target = max(lin_eta, eta1_factor x recent ||R_1||) (VCH_ETA1; 0 = off)
     double cg_scale_ratio;                // CG form: Dmax / Dmin beyond which a solve runs right-scaled (0 = never; VCH_CG_SCALE)
     // starting guess of a step's first Newton solve (k_guess): the first increments of the last GUESS_RING steps (ring,
     // written by k_dmu_ceiling_fin; the adjoint sweep keeps its levels there instead), the guess itself (also that of the
@@ -413,6 +414,8 @@ extern "C" vch2d_ctx *vch2d_create(const vch2d_params *p, int batch, int max_ste
     if (const char *e = getenv("VCH_CHEB_MARGIN")) c->cheb_margin = std::max(0, atoi(e));
     c->cheb_max = 6;           // plans longer than this (a wide spectrum: CG's adaptivity pays) keep the CG form
     if (const char *e = getenv("VCH_CHEB_MAX")) c->cheb_max = std::max(0, atoi(e));
+    c->eta1_factor = 1e-2;
+    if (const char *e = getenv("VCH_ETA1")) c->eta1_factor = atof(e);
     c->cg_scale_ratio = 4.0;
     if (const char *e = getenv("VCH_CG_SCALE")) c->cg_scale_ratio = atof(e);
     c->n_launch = c->n_sync = 0;
@@ -926,7 +929,7 @@ static int newton_level(vch2d_ctx *c, double dt, const double *un, const double 
     // VCH_FUSED=2: fused evaluation kernels, but the `fin` step as its own launch (no hand-off inside the launch)
     const bool fin_inside = c->fused_mode == 1;
     // CG-form solves whose diagonal spans more than cg_scale_ratio run on the right-scaled system (cg_weight, vch_kernels2d.h)
-    const SolveOpts so_{cheb_max_, spectral ? c->cg_scale_ratio : 0.0};
+    const SolveOpts so_{cheb_max_, spectral ? c->cg_scale_ratio : 0.0, in_march ? c->eta1_factor : 0.0};
     const EvalFin efin_{fin_inside ? c->fin_counter : (unsigned *)nullptr, c->hist_dev, c->P.kappa, c->lin_tol, eta_, so_};
     // starting guesses (marches on the stencil-free path only; forward_core fills the coefficient tables): of the first
     // solve here, of the second solve inside the residual trial of slot 0
@@ -980,11 +983,11 @@ static int newton_level(vch2d_ctx *c, double dt, const double *un, const double 
     if (c->debug_guess) {
         const TrajState &S = c->st_host[0];
         fprintf(stderr, "guess order %d / %d (run %d) | traj 0: ratio %.3e / %.3e solves %d sweeps %d %d %d normR %.3e active %d "
-                "tol %.3e %.3e %.3e kT %.6f %.6f %.6f form %d %d %d | norms %d total sweeps %ld newton %ld trials %d lastform %d lastn %d\n",
+                "tol %.3e %.3e %.3e kT %.6f %.6f %.6f form %d %d %d | norms %d total sweeps %ld newton %ld trials %d lastform %d lastn %d R %.3e %.3e %.3e r0 %.3e\n",
                 c->used1[0], c->used2[0], c->run2[0], S.guess_ratio, S.guess_ratio2, S.step_solves, S.step_lin[0],
                 S.step_lin[1], S.step_lin[2], S.normR, S.newton_active, S.step_tol[0], S.step_tol[1], S.step_tol[2],
                 S.step_kT[0], S.step_kT[1], S.step_kT[2], S.step_form[0], S.step_form[1], S.step_form[2], S.iters, S.lin_total,
-                S.newton_total, S.ntrials, S.use_cheb, S.cheb_n);
+                S.newton_total, S.ntrials, S.use_cheb, S.cheb_n, S.step_R[0], S.step_R[1], S.step_R[2], S.lin_r0);
     }
     int guard = 0;
     while (any_active()) {
