@@ -888,9 +888,16 @@ static int dmu_ceiling(vch2d_ctx *c, int strict) {
         if (inline_dmu && fused) {                                                                                          \
             GuessArgs gt_ = c->gtab2;                                                                                       \
             if (!tg_) memset(gt_.c, 0, sizeof(gt_.c));                                                                      \
-            LAUNCHC(PC_RESIDUAL, (k_eval<2>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s,     \
-                    c->Rphi_s, c->rhs_s, c->D_s, (const double *)c->xf, c->cphi, c->cmu, dt, c->part, (const double *)nullptr, \
-                    (const double *)nullptr, (const double *)nullptr, 0L, (double *)nullptr, gt_, c->x0g, efin_);           \
+            if (fin_inside)                                                                                                 \
+                LAUNCHC(PC_RESIDUAL, (k_eval<2, true>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s,    \
+                        c->mu_s, c->Rphi_s, c->rhs_s, c->D_s, (const double *)c->xf, c->cphi, c->cmu, dt, c->part,          \
+                        (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, 0L, (double *)nullptr,   \
+                        gt_, c->x0g, efin_);                                                                                \
+            else                                                                                                            \
+                LAUNCHC(PC_RESIDUAL, (k_eval<2, false>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s,   \
+                        c->mu_s, c->Rphi_s, c->rhs_s, c->D_s, (const double *)c->xf, c->cphi, c->cmu, dt, c->part,          \
+                        (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, 0L, (double *)nullptr,   \
+                        gt_, c->x0g, efin_);                                                                                \
             if (!fin_inside)                                                                                                \
                 LAUNCH((k_fin_residual<1>), dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->hist_dev, c->P.kappa, dt,     \
                        c->lin_tol, eta_, tg_ ? (int)c->gmask2 : 0, so_);                                              \
@@ -942,9 +949,14 @@ static int newton_level(vch2d_ctx *c, double dt, const double *un, const double 
         // step start in one launch: old-level terms, Newton start value, initial residual, starting guess (, `fin` step)
         GuessArgs g1_ = c->gtab1;
         if (!guess) memset(g1_.c, 0, sizeof(g1_.c));
-        LAUNCHC(PC_RESIDUAL0, (k_eval<0>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s, c->Rphi_s, c->rhs_s,
-                c->D_s, (const double *)nullptr, c->cphi, c->cmu, dt, c->part, (const double *)c->w, un, unp1, u_stride, c->wnew, g1_,
-                c->x0g, efin_);
+        if (fin_inside)
+            LAUNCHC(PC_RESIDUAL0, (k_eval<0, true>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s, c->Rphi_s,
+                    c->rhs_s, c->D_s, (const double *)nullptr, c->cphi, c->cmu, dt, c->part, (const double *)c->w, un, unp1, u_stride,
+                    c->wnew, g1_, c->x0g, efin_);
+        else
+            LAUNCHC(PC_RESIDUAL0, (k_eval<0, false>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s, c->Rphi_s,
+                    c->rhs_s, c->D_s, (const double *)nullptr, c->cphi, c->cmu, dt, c->part, (const double *)c->w, un, unp1, u_stride,
+                    c->wnew, g1_, c->x0g, efin_);
         if (!fin_inside)
             LAUNCH((k_fin_residual<2>), dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->hist_dev, c->P.kappa, dt, c->lin_tol, eta_,
                    guess ? (int)c->gmask1 : 0, so_);

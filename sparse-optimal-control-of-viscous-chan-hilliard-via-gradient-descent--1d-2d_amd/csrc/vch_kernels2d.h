@@ -1424,7 +1424,9 @@ __device__ __forceinline__ void fin_reduce_agent(const double *part, int nblk, i
                                // trajectories 0.533 -> 0.517 s, bench 5.17 -> 5.31; with the register cap lifted to fit them
                                // all, 122 VGPRs = 4 workgroups per CU: 0.551 s; profiles/r03_fused_ab.txt)
 #endif
-template <int MODE>
+// FIN_INSIDE: the hand-off variant (VCH_FUSED=1).  The default variant ends with the partials and carries neither the record
+// copy of the fin step (584 B of private memory per thread) nor the counter traffic.
+template <int MODE, bool FIN_INSIDE>
 __global__ __launch_bounds__(NTH, EVAL_MINBLK) void k_eval(Geom G, Phys P, TrajState *st, long slot_stride, double *phi_s, double *mu_s,
                                               double *Rphi_s, double *rhs_s, double *D_s, const double *dphi, double *cphi,
                                               double *cmu, double dt, double *part, const double *w, const double *un,
@@ -1735,20 +1737,21 @@ __global__ __launch_bounds__(NTH, EVAL_MINBLK) void k_eval(Geom G, Phys P, TrajS
                 const double a = sred[k * 4], bb = sred[k * 4 + 1], cc = sred[k * 4 + 2], dd = sred[k * 4 + 3];
                 const double v = op5[k] == 0 ? (a + bb) + (cc + dd)
                                              : (op5[k] == 1 ? fmin(fmin(a, bb), fmin(cc, dd)) : fmax(fmax(a, bb), fmax(cc, dd)));
-                if (fin.counter) store_agent(pp + k, v);
+                if (FIN_INSIDE) store_agent(pp + k, v);
                 else pp[k] = v;
             }
-            if (!fin.counter) return;             // a k_fin_residual launch follows
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const unsigned old = __hip_atomic_fetch_add(fin.counter + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_last = old == (unsigned)(nblk - 1) ? 1 : 0;
+            if (FIN_INSIDE) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned old = __hip_atomic_fetch_add(fin.counter + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_last = old == (unsigned)(nblk - 1) ? 1 : 0;
+            }
         }
-        if (!fin.counter) return;
+        if (!FIN_INSIDE) return;                  // a k_fin_residual launch follows
         __syncthreads();
         if (!s_last || threadIdx.x >= 64) return;
     }
     // ---- k_fin_residual, by the first wavefront of the last workgroup ----
-    {
+    if (FIN_INSIDE) {
         double v[NPART];
         const int op[NPART] = {0, 0, 1, 2, 0, 0};
         fin_reduce_agent(part, nblk, b, v, op, do_guess ? 5 : 4);
