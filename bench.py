@@ -65,7 +65,7 @@ ALG_BYTES = {
 }
 PMC_NAMES = {"cheb_rows": "k_cheb_rows<1024, 10, 0>", "cheb_rows_first": "k_cheb_rows<1024, 10, 1>", "cg_rows_fwd": "k_cg_rows_fwd<0, 1024, 10>",
              "schur_p": "k_schur_p<0>", "dct_rows_fwd": "k_dct_rows<0, 1024, 10>", "dct_cols": "k_dct_cols<1024, 10>",
-             "dct_rows_inv": "k_dct_rows<5, 1024, 10>", "residual": "k_eval<2>", "residual_first": "k_eval<0>", "adj_q": "k_adj_rows_fwd<0, 1024, 10>",
+             "dct_rows_inv": "k_dct_rows<5, 1024, 10>", "residual": "k_eval<2, false>", "residual_first": "k_eval<0, false>", "adj_q": "k_adj_rows_fwd<0, 1024, 10>",
              "guess": "k_guess", "adj_guess": "k_adj_guess", "adj_rhs": "k_adj_rhs"}
 
 
@@ -75,7 +75,7 @@ PMC_NAMES = {"cheb_rows": "k_cheb_rows<1024, 10, 0>", "cheb_rows_first": "k_cheb
 ROCPROF_NAMES = {"dct_cols": ("k_dct_cols<",), "dct_rows_inv": ("k_dct_rows<3", "k_dct_rows<4", "k_dct_rows<5"),
                  "dct_rows_fwd": ("k_dct_rows<0",), "cg_rows_fwd": ("k_cg_rows_fwd<0",), "cg_rows_fwd_first": ("k_cg_rows_fwd<1",),
                  "cheb_rows": ("k_cheb_rows<1024, 10, 0>",), "cheb_rows_first": ("k_cheb_rows<1024, 10, 1>",),
-                 "residual": ("k_eval<2>", "k_residual2", "k_residual<1>"), "residual_first": ("k_eval<0>", "k_residual<0>"),
+                 "residual": ("k_eval<2", "k_residual2", "k_residual<1>"), "residual_first": ("k_eval<0", "k_residual<0>"),
                  "adj_q": ("k_adj_rows_fwd<",), "guess": ("k_guess",), "adj_guess": ("k_adj_guess",),
                  "adj_rhs": ("k_adj_rhs",), "cg_update": ("k_cg_finish",), "cost": ("k_cost",), "prox": ("k_grad_prox",)}
 

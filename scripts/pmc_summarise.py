@@ -16,7 +16,7 @@ nodes = (N + 1) * (N + 1) * B
 #   "stream": 8 B/lane coalesced streaming reads (row FFT ingest, element-wise kernels), calibrated on k_grad_prox
 #   "tile":   8 B/lane reads of 64 x 16 tiles (the stencil kernels), calibrated on k_copy_plane (a pure tiled copy)
 alg = {"k_cheb_rows<1024, 10, 0>": (40, 16, "stream"), "k_cheb_rows<1024, 10, 1>": (16, 24, "stream"),
-       "k_eval<2>": (56, 40, "tile"), "k_eval<0>": (40, 64, "tile"),
+       "k_eval<2, false>": (56, 40, "tile"), "k_eval<0, false>": (40, 64, "tile"),
        "k_cg_rows_fwd<0, 1024, 10>": (40, 32, "stream"), "k_cg_rows_fwd<1, 1024, 10>": (16, 24, "stream"),
        "k_dct_rows<0, 1024, 10>": (8, 8, "stream"), "k_dct_rows<3, 1024, 10>": (16, 8, "stream"),
        "k_dct_rows<4, 1024, 10>": (24, 8, "stream"), "k_dct_rows<5, 1024, 10>": (24, 8, "stream"),

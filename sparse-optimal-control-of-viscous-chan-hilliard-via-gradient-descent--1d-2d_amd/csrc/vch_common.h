@@ -55,7 +55,10 @@ struct Geom {
 };
 
 constexpr int TX = 64;      // tile extent along the fast axis (one wavefront wide)
-constexpr int TY = 16;      // tile extent along the slow axis
+#ifndef VCH_TY
+#define VCH_TY 16
+#endif
+constexpr int TY = VCH_TY;  // tile extent along the slow axis (A/B knob: 8 or 16; every thread owns TY / 4 rows)
 constexpr int NTH = 256;    // threads per workgroup = 4 wavefronts
 constexpr int NPART = 6;    // partial-reduction slots per workgroup
 
