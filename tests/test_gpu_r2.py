@@ -681,3 +681,47 @@ def test_starting_guesses_ragged_steps_and_switching_control(V, O2):
     ph0, st0 = march({"VCH_GUESS": "0"})
     assert counts(st) == counts(st0), (st, st0)
     assert np.max(np.abs(ph - ph0)) < 1e-9
+
+
+def test_at_size_self_consistency_512(V, O2):
+    """AT THE BENCHED GRID (512^2, 120 steps, two trajectories): everything the march does to be fast -- the forcing rules of
+    the Newton solves, the reduction-free sweeps, the starting guesses, the 1e-12 adjoint tolerance of the PGD loop -- against
+    the same engine with every solve started from zero and taken to round-off (VCH_LIN_ETA=0, VCH_GUESS=0,
+    VCH_ADJ_TOL=1e-15): a march under a control of the size the line search produces (|u| up to 3) takes the same Newton
+    iterations, solves and Armijo trials and ends within 1e-9 of it; three PGD iterations make the same line-search
+    decisions and reach the same costs to 1e-9."""
+    N, M, B = 512, 120, 2
+    t, dts = V.time_grid(M * 1e-3, 1e-3)
+    phi0 = np.stack([O2.init_phi_random(N, N, 1e-2, amp=0.1, seed=42 + i) for i in range(B)])
+    xs = np.linspace(0, 1, N + 1)
+    shape = np.sin(2 * np.pi * xs)[:, None] * np.cos(np.pi * xs)[None, :]
+    u = np.stack([a * np.linspace(0, 1, M + 1)[:, None, None] * shape[None] for a in (3.0, -2.0)])
+    phi_T = np.broadcast_to(_phi_T(N), phi0.shape).copy()
+    exact = {"VCH_LIN_ETA": "0", "VCH_GUESS": "0", "VCH_ADJ_TOL": "1e-15"}
+
+    def run(env):
+        for k, v in env.items():
+            os.environ[k] = v
+        try:
+            e = V.Engine2D(Nx=N, Ny=N, batch=B, max_steps=M)
+            ph, st = e.forward(phi0, dts, u=u)
+            last = ph[:, -1].copy()
+            mid = ph[:, M // 2].copy()
+            del ph
+            J0 = e.pgd_init(phi0, phi_T, t, V.make_opt(), ramp=True, T=M * 1e-3)
+            out = e.pgd_iterate(3)
+            e.close()
+            return last, mid, st, J0, out
+        finally:
+            for k in env:
+                del os.environ[k]
+    counts = lambda s: (s["newton_iters"], s["linear_solves"], s["armijo_trials"])
+    la, ma, sa, Ja, oa = run({})
+    lb, mb, sb, Jb, ob = run(exact)
+    assert counts(sa) == counts(sb), (sa, sb)
+    assert sa["linear_iters"] < 0.5 * sb["linear_iters"], (sa, sb)          # and it is the cheap path that ran
+    assert np.max(np.abs(la - lb)) < 1e-9 and np.max(np.abs(ma - mb)) < 1e-9
+    assert np.allclose(Ja, Jb, rtol=1e-10, atol=1e-12)
+    assert np.array_equal(oa["attempts"], ob["attempts"]), (oa["attempts"], ob["attempts"])
+    assert np.allclose(oa["cost"], ob["cost"], rtol=1e-9, atol=0.0), (oa["cost"], ob["cost"])
+    assert np.allclose(oa["alpha"], ob["alpha"], rtol=0.0, atol=0.0)
