@@ -8,7 +8,7 @@ the build container, imports the reference from /root/reference, copies nothing,
                         rows), default K1 weights: natural march, adjoint sweep on it, cost, and three iterations of
                         the PGD loop G1:353-480 (costs, step lengths, trial counts, final control and state, error
                         metrics through make_golden_r2.errs_1d)
-  g2d_stress_1024.npz   (only with --only stress1024: tens of minutes) the same at BASELINE config 5's own grid, 2 steps
+  g2d_stress_1024.npz   (only with --only stress1024: HOURS of SuperLU time) the same at BASELINE config 5's own grid, first step only
   g2d_stress_256.npz    amp = 1.0 start at 256^2 (the FFT path, twice the size of g2d_stress_128), dt = 1e-3, 3 steps:
                         Newton residual histories and residual-evaluation counts per step (F2:377-423: step ceiling,
                         Armijo, best-trial fallback), sub-sampled fields, per-level norms
