@@ -139,6 +139,10 @@ struct vch2d_ctx {
     double *tmp[6];
     double *wts_mass, *W_cost;            // single planes
     double *part;                         // [B][nblk][NPART]
+    double *part_mass;                    // [B][nblk][NPART]: k_mass's partials (read by the NEXT kernel: k_post or k_eval<0>)
+    bool post_fold;                       // VCH_POST_FOLD (default 1): the end of a step is applied by the next step's k_eval<0>
+    bool post_pending;                    // a step's clip / mass fix / history store waits for the next k_eval<0>
+    double *post_hist;                    // ... its history level (or NULL)
     TrajState *st, *st_host;
     // look at the device state without a copy command and a stream wait: a one-workgroup kernel writes the records into
     // mapped host memory (st_pub) and then a sequence number (seq_pub) the host spins on (sync_state)
@@ -409,6 +413,10 @@ extern "C" vch2d_ctx *vch2d_create(const vch2d_params *p, int batch, int max_ste
     // with the fin step as its own launch 0.523 s -- the default
     c->fused_mode = getenv("VCH_FUSED") ? atoi(getenv("VCH_FUSED")) : 2;
     c->fused_on = c->fused_mode != 0;
+    c->post_fold = true;
+    if (const char *e = getenv("VCH_POST_FOLD")) c->post_fold = atoi(e) != 0;
+    c->post_pending = false;
+    c->post_hist = nullptr;
     c->fin_counter = nullptr;
     for (int &n : c->spec_chn) n = 2;
     c->cheb_margin = 1;
@@ -439,6 +447,7 @@ extern "C" vch2d_ctx *vch2d_create(const vch2d_params *p, int batch, int max_ste
         if (dalloc(q, bp, c->stream)) return fail("hipMalloc");
     if (dalloc(&c->wts_mass, G.plane, c->stream) || dalloc(&c->W_cost, G.plane, c->stream)) return fail("hipMalloc");
     if (dalloc(&c->part, (size_t)batch * c->nblk * NPART, c->stream)) return fail("hipMalloc");
+    if (dalloc(&c->part_mass, (size_t)batch * c->nblk * NPART, c->stream)) return fail("hipMalloc");
     c->gnblk = ((G.nf + GN - 1) / GN) * ((G.ns + GM - 1) / GM);
     if (dalloc(&c->gpart, 2 * (size_t)batch * (c->gnblk + G.ns), c->stream)) return fail("hipMalloc");
     c->gpart2 = c->gpart + (size_t)batch * (c->gnblk + G.ns);
@@ -570,7 +579,7 @@ extern "C" void vch2d_destroy(vch2d_ctx *c) {
     hipStreamSynchronize(c->stream);
     double *all[] = {c->phi_s, c->mu_s, c->Rphi_s, c->rhs_s, c->D_s, c->w, c->wnew, c->mu0, c->cphi, c->cmu, c->x,
                      c->r, c->dmu, c->t1, c->t2, c->cg_p[0], c->cg_p[1], c->cg_v, c->cg_q, c->cg_z2, c->xf, c->dprev[0], c->dprev[1], c->dprev[2], c->dprev[3], c->dprev[4], c->dprev[5], c->dprev[6], c->dprev[7], c->dprev2[0], c->dprev2[1], c->dprev2[2], c->dprev2[3], c->dprev2[4], c->dprev2[5], c->dprev2[6], c->dprev2[7], c->x0g, c->gpart, c->gpart3, c->tmp[0], c->tmp[1], c->tmp[2], c->tmp[3], c->tmp[4], c->tmp[5],
-                     c->phiT, c->phi0, c->wts_mass, c->W_cost, c->part, c->hist_dev, c->alpha_dev, c->J_dev, c->Q1f,
+                     c->phiT, c->phi0, c->wts_mass, c->W_cost, c->part, c->part_mass, c->hist_dev, c->alpha_dev, c->J_dev, c->Q1f,
                      c->Q2f, c->Q1s, c->Q2s, c->mf, c->ms, c->phi_hist, c->u_hist, c->u_trial, c->phi_trial, c->phiQ,
                      c->r_hist, c->p_hist, c->q_hist, c->cost_part, c->cost_lvl, c->tfrac_dev};
     for (double *q : all)
@@ -892,12 +901,12 @@ static int dmu_ceiling(vch2d_ctx *c, int strict) {
                 LAUNCHC(PC_RESIDUAL, (k_eval<2, true>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s,    \
                         c->mu_s, c->Rphi_s, c->rhs_s, c->D_s, (const double *)c->xf, c->cphi, c->cmu, dt, c->part,          \
                         (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, 0L, (double *)nullptr,   \
-                        gt_, c->x0g, efin_);                                                                                \
+                        gt_, c->x0g, efin_, PostArgs{nullptr, nullptr, 0});                                                 \
             else                                                                                                            \
                 LAUNCHC(PC_RESIDUAL, (k_eval<2, false>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s,   \
                         c->mu_s, c->Rphi_s, c->rhs_s, c->D_s, (const double *)c->xf, c->cphi, c->cmu, dt, c->part,          \
                         (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, 0L, (double *)nullptr,   \
-                        gt_, c->x0g, efin_);                                                                                \
+                        gt_, c->x0g, efin_, PostArgs{nullptr, nullptr, 0});                                                 \
             if (!fin_inside)                                                                                                \
                 LAUNCH((k_fin_residual<1>), dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->hist_dev, c->P.kappa, dt,     \
                        c->lin_tol, eta_, tg_ ? (int)c->gmask2 : 0, so_);                                              \
@@ -949,14 +958,17 @@ static int newton_level(vch2d_ctx *c, double dt, const double *un, const double 
         // step start in one launch: old-level terms, Newton start value, initial residual, starting guess (, `fin` step)
         GuessArgs g1_ = c->gtab1;
         if (!guess) memset(g1_.c, 0, sizeof(g1_.c));
+        // the previous step's clip / mass fix / history store, if forward_core left it to this kernel
+        const PostArgs post_{c->post_pending ? (const double *)c->part_mass : (const double *)nullptr, c->post_hist, hist_stride(c)};
+        c->post_pending = false;
         if (fin_inside)
             LAUNCHC(PC_RESIDUAL0, (k_eval<0, true>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s, c->Rphi_s,
                     c->rhs_s, c->D_s, (const double *)nullptr, c->cphi, c->cmu, dt, c->part, (const double *)c->w, un, unp1, u_stride,
-                    c->wnew, g1_, c->x0g, efin_);
+                    c->wnew, g1_, c->x0g, efin_, post_);
         else
             LAUNCHC(PC_RESIDUAL0, (k_eval<0, false>), c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, c->mu_s, c->Rphi_s,
                     c->rhs_s, c->D_s, (const double *)nullptr, c->cphi, c->cmu, dt, c->part, (const double *)c->w, un, unp1, u_stride,
-                    c->wnew, g1_, c->x0g, efin_);
+                    c->wnew, g1_, c->x0g, efin_, post_);
         if (!fin_inside)
             LAUNCH((k_fin_residual<2>), dim3(c->B), dim3(64), c->st, c->part, c->nblk, c->hist_dev, c->P.kappa, dt, c->lin_tol, eta_,
                    guess ? (int)c->gmask1 : 0, so_);
@@ -1397,6 +1409,9 @@ static int forward_core(vch2d_ctx *c, const double *u_dev, int u_rows, const dou
     LAUNCH(k_init_mu, c->grid, dim3(NTH), c->G, c->P, c->phi_s, c->w, c->mu_s);
     LAUNCH(k_mass, c->grid, dim3(NTH), c->G, c->st, c->slot_stride, c->phi_s, c->wts_mass, 0, c->part);
     LAUNCH(k_fin_mass, dim3(c->B), dim3(64), c->st, c->part, c->nblk, 1);
+    c->post_pending = false;
+    // marches whose steps start with k_eval<0> (newton_level: the fused path) leave the end of every step but the last to it
+    const bool fold_post = c->post_fold && c->fused_on && c->use_fft && !c->half_f && !c->half_s;
     if (hist_out) LAUNCH(k_copy_plane, c->grid, dim3(NTH), c->G, c->phi_s, c->G.plane, hist_out, hs);
     const bool per_traj = c->B <= GUESS_BMAX;
     for (auto &q : c->pol1) q.reset();
@@ -1470,9 +1485,14 @@ static int forward_core(vch2d_ctx *c, const double *u_dev, int u_rows, const dou
         }
         VCHCHK(newton_level(c, dt[step], un, unp1, hs, nullptr, true));
         // clip, mass fix, store (F2:562-585)
-        LAUNCH(k_mass, c->grid, dim3(NTH), c->G, c->st, c->slot_stride, c->phi_s, c->wts_mass, 1, c->part);
-        LAUNCH(k_post, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s,
-               hist_out ? hist_out + (long)(step + 1) * c->G.plane : (double *)nullptr, hs, (const double *)c->part);
+        LAUNCH(k_mass, c->grid, dim3(NTH), c->G, c->st, c->slot_stride, c->phi_s, c->wts_mass, 1, c->part_mass);
+        double *const lvl = hist_out ? hist_out + (long)(step + 1) * c->G.plane : (double *)nullptr;
+        if (fold_post && step + 1 < M) {
+            c->post_pending = true;
+            c->post_hist = lvl;
+        } else {
+            LAUNCH(k_post, c->grid, dim3(NTH), c->G, c->P, c->st, c->slot_stride, c->phi_s, lvl, hs, (const double *)c->part_mass);
+        }
         std::swap(c->w, c->wnew);
         if (c->guess_on) {
             // what each guess achieved decides the order of that trajectory's next one (GuessPolicy); the second solves' ring

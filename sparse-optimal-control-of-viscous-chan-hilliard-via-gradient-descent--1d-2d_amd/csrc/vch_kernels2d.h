@@ -754,13 +754,9 @@ __global__ __launch_bounds__(NTH) void k_mass(Geom G, const TrajState *__restric
 
 // k_post sums the per-workgroup partials of k_mass itself (every workgroup, the same numbers in the same order: the
 // first wavefront strides over them like fin_reduce does), so no `fin` launch sits between the two passes.
-__global__ __launch_bounds__(NTH) void k_post(Geom G, Phys P, const TrajState *__restrict__ st, long slot_stride,
-                                              double *__restrict__ phi_s, double *__restrict__ hist_level,
-                                              long hist_stride, const double *__restrict__ part) {
-    TILE_COORDS;
-    const TrajState S = st[b];
-    if (S.frozen) return;
-    __shared__ double sm[2];
+// The same two pieces serve k_eval<0>, which applies the end of step n to the values it loads at the start of step n + 1
+// (PostArgs): post_sums (first wavefront, then a barrier) and PostFix::apply (a pure function of the node's value).
+__device__ __forceinline__ void post_sums(const double *__restrict__ part, int nblk, int b, double *sm2) {
     if (threadIdx.x < 64) {
         double a0 = 0.0, a1 = 0.0;
         for (int t = threadIdx.x; t < nblk; t += 64) {
@@ -770,29 +766,55 @@ __global__ __launch_bounds__(NTH) void k_post(Geom G, Phys P, const TrajState *_
         a0 = wave_sum(a0);
         a1 = wave_sum(a1);
         if (threadIdx.x == 0) {
-            sm[0] = a0;
-            sm[1] = a1;
+            sm2[0] = a0;
+            sm2[1] = a1;
         }
     }
+}
+struct PostFix {
+    double shift, hi;
+    bool fix, interior_ok;
+    __device__ __forceinline__ PostFix(const double *sm2, double mass0, double LxLy) {
+        const double mass_err = sm2[0] - mass0, Wint = sm2[1];
+        hi = 1.0 - DELTA_SEP;
+        fix = fabs(mass_err) > 1e-16;
+        interior_ok = Wint > 0.0;
+        shift = fix ? (interior_ok ? mass_err / Wint : mass_err / LxLy) : 0.0;
+    }
+    __device__ __forceinline__ double apply(double v) const {
+        double ph = fmin(fmax(v, -hi), hi);
+        if (fix) {
+            if (interior_ok) {
+                if (fabs(ph) < hi - 5e-3) ph -= shift;
+            } else {
+                ph = fmin(fmax(ph - shift, -hi), hi);
+            }
+        }
+        return ph;
+    }
+};
+struct PostArgs {
+    const double *part;        // k_mass partials of the step that has just ended (own buffer), or NULL: nothing pending
+    double *hist;              // history level of that step, or NULL
+    long hist_stride;
+};
+
+__global__ __launch_bounds__(NTH) void k_post(Geom G, Phys P, const TrajState *__restrict__ st, long slot_stride,
+                                              double *__restrict__ phi_s, double *__restrict__ hist_level,
+                                              long hist_stride, const double *__restrict__ part) {
+    TILE_COORDS;
+    const TrajState S = st[b];
+    if (S.frozen) return;
+    __shared__ double sm[2];
+    post_sums(part, nblk, b, sm);
     __syncthreads();
-    const double mass_err = sm[0] - S.mass0, Wint = sm[1];
-    const double hi = 1.0 - DELTA_SEP;
-    const bool fix = fabs(mass_err) > 1e-16;
-    const bool interior_ok = Wint > 0.0;
-    const double shift = fix ? (interior_ok ? mass_err / Wint : mass_err / P.LxLy) : 0.0;
+    const PostFix pf(sm, S.mass0, P.LxLy);
     for (int k = 0; k < TY / 4; ++k) {
         int r = r0 + ly0 + 4 * k, c = c0 + lx;
         if (r < G.ns && c < G.nf) {
             long o = (long)r * G.pitch + c;
             long os = S.slot * slot_stride + b * G.plane + o;
-            double ph = fmin(fmax(phi_s[os], -hi), hi);
-            if (fix) {
-                if (interior_ok) {
-                    if (fabs(ph) < hi - 5e-3) ph -= shift;
-                } else {
-                    ph = fmin(fmax(ph - shift, -hi), hi);
-                }
-            }
+            const double ph = pf.apply(phi_s[os]);
             phi_s[os] = ph;
             if (hist_level) hist_level[b * hist_stride + o] = ph;
         }
@@ -1431,7 +1453,7 @@ __global__ __launch_bounds__(NTH, EVAL_MINBLK) void k_eval(Geom G, Phys P, TrajS
                                               double *Rphi_s, double *rhs_s, double *D_s, const double *dphi, double *cphi,
                                               double *cmu, double dt, double *part, const double *w, const double *un,
                                               const double *unp1, long u_stride, double *wnew, GuessArgs ga, double *x0,
-                                              EvalFin fin) {
+                                              EvalFin fin, PostArgs post) {
     TILE_COORDS;
     // only the few fields the evaluation needs are read here; the record as a whole is read, advanced and written back by
     // one thread of the workgroup that finishes last (a per-thread copy of the record would live in private memory)
@@ -1464,7 +1486,33 @@ __global__ __launch_bounds__(NTH, EVAL_MINBLK) void k_eval(Geom G, Phys P, TrajS
     if (MODE == 0) {
         // ---- k_prepare + k_residual<0> ----
         constexpr int N1 = (TY + 2) * W1, I1 = (N1 + NTH - 1) / NTH;      // halo-1 elements, per thread
-        load_tile<2>(sp, phi_s + src * slot_stride + pb, G, c0, r0);
+        if (post.part) {
+            // the end of the previous step (F2:562-577: clip, mass fix, history) applied to the level as it is loaded: the sums
+            // of k_mass's partials by the first wavefront while everybody's loads are in flight, then the fix in registers
+            __shared__ double s_post[2];
+            constexpr int I2 = (W2 * (TY + 4) + NTH - 1) / NTH;
+            double raw[I2];
+#pragma unroll
+            for (int i = 0; i < I2; ++i) {
+                const int e = threadIdx.x + i * NTH;
+                raw[i] = 0.0;
+                if (e < W2 * (TY + 4)) {
+                    int ly = e / W2, lxx = e - ly * W2;
+                    int gr = refl(r0 - 2 + ly, G.ns), gc = refl(c0 - 2 + lxx, G.nf);
+                    raw[i] = phi_s[src * slot_stride + pb + (long)gr * G.pitch + gc];
+                }
+            }
+            post_sums(post.part, nblk, (int)b, s_post);
+            __syncthreads();
+            const PostFix pf(s_post, st[b].mass0, P.LxLy);
+#pragma unroll
+            for (int i = 0; i < I2; ++i) {
+                const int e = threadIdx.x + i * NTH;
+                if (e < W2 * (TY + 4)) sp[e] = pf.apply(raw[i]);
+            }
+        } else {
+            load_tile<2>(sp, phi_s + src * slot_stride + pb, G, c0, r0);
+        }
         load_tile<1>(sm, mu_s + src * slot_stride + pb, G, c0, r0);          // mu of the old level
 #if EVAL_PREFETCH
         double vW[I1], vU0[I1], vU1[I1];
@@ -1533,6 +1581,7 @@ __global__ __launch_bounds__(NTH, EVAL_MINBLK) void k_eval(Geom G, Phys P, TrajS
                 const double rhv = -rmv + lap_at<W1>(sr, p1, G.ax, G.ay);
                 const double d = jac_diag(ph, tdt, P.c1);
                 phi_s[od] = ph;
+                if (post.part && post.hist) post.hist[b * post.hist_stride + (long)r * G.pitch + c] = ph;
                 mu_s[od] = sm[p1];
                 Rphi_s[od] = rp;
                 D_s[od] = d;

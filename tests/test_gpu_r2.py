@@ -563,6 +563,11 @@ def test_fused_evaluation_kernels_bit_identical(V, O2):
     (ph1, st1), (ph1b, _) = march({"VCH_FUSED": "1"})
     assert np.array_equal(ph, ph1) and np.array_equal(ph, ph1b) and key(st1) == key(st)
     assert st1["launches"] < st["launches"], (st1, st)
+    # the end of a step (clip, mass fix, history store: F2:562-577) applied by the next step's k_eval<0> to the values it
+    # loads, against k_post after every step (VCH_POST_FOLD=0): every stored level bit for bit, one launch less per step
+    (ph2, st2), _ = march({"VCH_POST_FOLD": "0"})
+    assert np.array_equal(ph, ph2) and key(st2) == key(st)
+    assert st2["launches"] - st["launches"] == M - 1, (st, st2)
 
 
 def test_adjoint_sweep_schedule_independent(V, O2):
