@@ -577,6 +577,66 @@ def test_config4_shape_two_contexts_of_four_512(V, O2):
     e1.close()
 
 
+def test_config4_full_size_eight_trajectories_512x1000(V, O2):
+    """BASELINE config 4's per-GPU share AT FULL SIZE and in the benched shape: 512^2, 1000 steps of 1e-3, 8 trajectories
+    (seeds 42..49) as two concurrent contexts of 4, one device-resident PGD iteration (adjoint sweep, optimistic march, line
+    search).  Size-independent properties for every trajectory -- the cost decreases, the controlled state conserves mass
+    and stays inside the clip band, the control respects the box -- and two of the eight (one per context) reproduce
+    their own single-trajectory run of the same 1000 steps bit for bit: cost, step length, attempts, control, state."""
+    import threading
+    F2 = V.module("Vch_control_2D.Forward2_solver")
+    N, M = 512, 1000
+    t, dts = V.time_grid(1.0, 1e-3)
+    xs = np.linspace(0, 1, N + 1)
+    phi_T = 0.7 * np.sin(2 * np.pi * xs)[:, None] * np.cos(np.pi * xs)[None, :]
+    phi0 = np.stack([F2.init_phi_random(N, N, 1e-2, amp=0.1, seed=42 + i) for i in range(8)])
+    opt = V.make_opt()
+    wts = np.outer(F2.trapz_weights(N + 1), F2.trapz_weights(N + 1))
+    lv = list(range(0, M + 1, 100))
+    engs = [V.Engine2D(Nx=N, Ny=N, batch=4, max_steps=M) for _ in range(2)]
+    out, err = [None, None], []
+    probe = {0: 1, 1: 2}                                   # context -> the trajectory of it that is compared with a single run
+
+    def work(k):
+        try:
+            e = engs[k]
+            J0 = e.pgd_init(phi0[4 * k:4 * k + 4], np.stack([phi_T] * 4), t, opt, ramp=True, T=1.0)
+            r = e.pgd_iterate(1)
+            u, ph = e.pgd_get("u"), e.pgd_get("phi")
+            checks = []
+            for b in range(4):
+                mass = np.array([np.sum(wts * ph[b, j]) for j in lv])
+                checks.append((float(np.abs(mass - mass[0]).max()), float(np.abs(ph[b]).max()), float(u[b].min()), float(u[b].max()),
+                               bool(np.isfinite(ph[b]).all())))
+            b = probe[k]
+            out[k] = (J0, r, u[b].copy(), ph[b].copy(), checks)
+        except BaseException as exc:          # surfaces in the main thread
+            err.append(exc)
+    ths = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    for e in engs:
+        e.close()
+    assert not err, err
+    for k in range(2):
+        J0, r, _, _, checks = out[k]
+        assert np.all(r["cost"][:, 0] < J0[:, 4]) and np.all(r["attempts"][:, 0] <= 10) and np.all(r["alpha"][:, 0] <= 50.0)
+        for dm, amax, umin, umax, fin in checks:
+            assert dm <= 1e-10 * np.sum(wts) and amax <= 0.99 + 1e-15 and umin >= -1.0 and umax <= 1.0 and fin
+    e1 = V.Engine2D(Nx=N, Ny=N, batch=1, max_steps=M)
+    for k in range(2):
+        J0, r, u, ph, _ = out[k]
+        b = probe[k]
+        J1 = e1.pgd_init(phi0[4 * k + b], phi_T, t, opt, ramp=True, T=1.0)
+        r1 = e1.pgd_iterate(1)
+        assert np.array_equal(J0[b], J1[0]) and np.array_equal(r["cost"][b], r1["cost"][0]), (k, r["cost"][b], r1["cost"][0])
+        assert np.array_equal(r["attempts"][b], r1["attempts"][0]) and np.array_equal(r["alpha"][b], r1["alpha"][0])
+        assert np.array_equal(u, e1.pgd_get("u")) and np.array_equal(ph, e1.pgd_get("phi")), k
+    e1.close()
+
+
 def test_bitwise_reproducibility(V, O2):
     """All reductions run in a fixed order (per-workgroup partials summed by index, no atomics): two runs of the
     same march / PGD iteration give bit-identical histories, controls and costs, also from different contexts."""
