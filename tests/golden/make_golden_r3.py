@@ -8,7 +8,8 @@ the build container, imports the reference from /root/reference, copies nothing,
                         rows), default K1 weights: natural march, adjoint sweep on it, cost, and three iterations of
                         the PGD loop G1:353-480 (costs, step lengths, trial counts, final control and state, error
                         metrics through make_golden_r2.errs_1d)
-  g2d_stress_1024.npz   (only with --only stress1024: HOURS of SuperLU time) the same at BASELINE config 5's own grid, first step only
+  g2d_stress_1024.npz   (only with --only stress1024) the same at BASELINE config 5's own grid, first step only.  NOT committed: the
+                        reference's first Newton call there had not returned after 5 h 45 min of SuperLU time in the build container
   g2d_stress_256.npz    amp = 1.0 start at 256^2 (the FFT path, twice the size of g2d_stress_128), dt = 1e-3, 3 steps:
                         Newton residual histories and residual-evaluation counts per step (F2:377-423: step ceiling,
                         Armijo, best-trial fallback), sub-sampled fields, per-level norms
@@ -116,8 +117,8 @@ def gen_stress256():
 
 
 def gen_stress1024():
-    """BASELINE config 5's own grid: the FIRST step of the reference at 1024^2 (2.1 M unknowns per SuperLU solve, ~20 min each; the second step would run
-    hundreds of damped Newton iterations)."""
+    """BASELINE config 5's own grid: the FIRST step of the reference at 1024^2 (SuperLU on a 4.2 M-row block system per Newton
+    iteration: more than an hour each here; the second step would run hundreds of damped Newton iterations)."""
     gen_stress(1024, 1, 16, "g2d_stress_1024.npz")
 
 

@@ -335,7 +335,7 @@ def test_stress_256_vs_reference(V, O2):
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g2d_stress_1024.npz")),
-                    reason="the 1024^2 reference golden takes hours of SuperLU time to make (make_golden_r3.py --only stress1024)")
+                    reason="no 1024^2 reference golden: the reference's first Newton call there did not finish in 5 h 45 min (make_golden_r3.py --only stress1024)")
 def test_stress_1024_vs_reference(V, O2):
     """BASELINE config 5's own grid: the FIRST step at 1024^2 (four SuperLU solves of 2.1 M unknowns, hours of reference time)
     against the reference's run: Newton history, residual evaluations, field."""
