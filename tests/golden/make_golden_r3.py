@@ -8,6 +8,7 @@ the build container, imports the reference from /root/reference, copies nothing,
                         rows), default K1 weights: natural march, adjoint sweep on it, cost, and three iterations of
                         the PGD loop G1:353-480 (costs, step lengths, trial counts, final control and state, error
                         metrics through make_golden_r2.errs_1d)
+  g2d_stress_512.npz    (only with --only stress512: about an hour) the same at the benched grid 512^2, first step only
   g2d_stress_1024.npz   (only with --only stress1024) the same at BASELINE config 5's own grid, first step only.  NOT committed: the
                         reference's first Newton call there had not returned after 5 h 45 min of SuperLU time in the build container
   g2d_stress_256.npz    amp = 1.0 start at 256^2 (the FFT path, twice the size of g2d_stress_128), dt = 1e-3, 3 steps:
@@ -116,6 +117,12 @@ def gen_stress256():
     gen_stress(256, 3, 4, "g2d_stress_256.npz")
 
 
+def gen_stress512():
+    """The near-singular start at the benched grid, 512^2: the first step of the reference (four SuperLU solves of the 1 M-row
+    block system)."""
+    gen_stress(512, 1, 8, "g2d_stress_512.npz")
+
+
 def gen_stress1024():
     """BASELINE config 5's own grid: the FIRST step of the reference at 1024^2 (SuperLU on a 4.2 M-row block system per Newton
     iteration: more than an hour each here; the second step would run hundreds of damped Newton iterations)."""
@@ -124,13 +131,13 @@ def gen_stress1024():
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", choices=["config1", "stress256", "stress1024"])
+    ap.add_argument("--only", choices=["config1", "stress256", "stress512", "stress1024"])
     a = ap.parse_args()
     if not os.path.isdir(REF):
         sys.exit("reference checkout not present: golden vectors can only be regenerated in the build container")
     os.chdir(tempfile.mkdtemp(prefix="vch_golden_"))
     import warnings
     warnings.filterwarnings("ignore")
-    for name, fn in (("config1", gen_config1), ("stress256", gen_stress256), ("stress1024", gen_stress1024)):
-        if a.only == name or (a.only is None and name != "stress1024"):
+    for name, fn in (("config1", gen_config1), ("stress256", gen_stress256), ("stress512", gen_stress512), ("stress1024", gen_stress1024)):
+        if a.only == name or (a.only is None and name not in ("stress512", "stress1024")):
             print(name); fn()
