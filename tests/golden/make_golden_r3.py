@@ -8,7 +8,8 @@ the build container, imports the reference from /root/reference, copies nothing,
                         rows), default K1 weights: natural march, adjoint sweep on it, cost, and three iterations of
                         the PGD loop G1:353-480 (costs, step lengths, trial counts, final control and state, error
                         metrics through make_golden_r2.errs_1d)
-  g2d_stress_512.npz    (only with --only stress512: about an hour) the same at the benched grid 512^2, first step only
+  g2d_stress_512.npz    (only with --only stress512) the same at the benched grid 512^2, first step only.  NOT committed: the first
+                        Newton call had not returned after 2 h 50 min of SuperLU time in the build container
   g2d_stress_1024.npz   (only with --only stress1024) the same at BASELINE config 5's own grid, first step only.  NOT committed: the
                         reference's first Newton call there had not returned after 5 h 45 min of SuperLU time in the build container
   g2d_stress_256.npz    amp = 1.0 start at 256^2 (the FFT path, twice the size of g2d_stress_128), dt = 1e-3, 3 steps:

@@ -335,7 +335,7 @@ def test_stress_256_vs_reference(V, O2):
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g2d_stress_512.npz")),
-                    reason="no 512^2 stress golden (make_golden_r3.py --only stress512: about an hour of SuperLU time)")
+                    reason="no 512^2 stress golden: the reference's first Newton call there did not finish in 2 h 50 min (make_golden_r3.py --only stress512)")
 def test_stress_512_vs_reference(V, O2):
     """The near-singular start at the BENCHED grid (512^2, amp = 1.0, dt = 1e-3), first step, against the reference's own
     run: Newton history (same length, same values above the evaluation floor), residual evaluations, field."""
